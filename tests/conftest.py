@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def golden_constants(golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "constants.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_manifest(golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "manifest.json")) as f:
+        return json.load(f)

@@ -1,0 +1,378 @@
+"""Pins the CPU oracle (oracle/) against the reference's own golden vectors.
+
+CPU-only; nothing here touches the GPU product path.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+LITERAL_ENTRY = 0x8000
+EXCEPTIONAL_ENTRY = 0x4000
+SECONDARY_TABLE_ENTRY = 0x2000
+
+
+def fixed_code_lengths():
+    # src/tables.rs:207-232 make_fixed_code_lengths
+    return [8] * 144 + [9] * 112 + [7] * 24 + [8] * 8 + [5] * 32
+
+
+# ---- constants (src/tables.rs, src/compress/ultrafast.rs:82-86) -------------------------
+
+def test_constant_tables_match_reference_data(golden_constants):
+    assert ob.const_array("fdo_huffman_lengths", 286, np.int64).tolist() == golden_constants["HUFFMAN_LENGTHS"]
+    assert ob.const_array("fdo_ultrafast_header", 54, np.int64).tolist() == golden_constants["ULTRAFAST_HEADER"]
+
+
+def test_length_tables_self_consistent(golden_constants):
+    # src/decompress.rs:1198-1216 `tables` test, applied to the reference's literal arrays:
+    # the oracle derives LENGTH_TO_SYMBOL/LEN_EXTRA from the RFC base/extra tables, so the
+    # encoder's run symbols must agree with the reference data for every run length.
+    lts = golden_constants["LENGTH_TO_SYMBOL"]
+    lte = golden_constants["LENGTH_TO_LEN_EXTRA"]
+    base = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99,
+            115, 131, 163, 195, 227, 258]
+    extra = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+    for i, bits in enumerate(extra):
+        for j in range(1 << bits):
+            if i == 27 and j == 31:
+                continue
+            assert lte[base[i] + j - 3] == bits
+            assert lts[base[i] + j - 3] == i + 257
+    assert lts[255] == 285 and lte[255] == 0
+
+
+def test_huffman_codes_are_canonical(golden_constants):
+    # src/lib.rs:103-127 compute_codes: canonical, bit-reversed
+    lengths = golden_constants["HUFFMAN_LENGTHS"]
+    codes = ob.const_array("fdo_huffman_codes", 286, np.int64).tolist()
+    code = 0
+    for ln in range(1, 17):
+        for i, l in enumerate(lengths):
+            if l == ln:
+                rev = int(format(code, "0%db" % ln)[::-1], 2)
+                assert codes[i] == rev
+                code += 1
+        code <<= 1
+    assert code == 2 << 16
+    assert codes[0] == 0 and lengths[0] == 2 and lengths[285] == 9 and lengths[256] == 12
+
+
+# ---- golden decode tables (src/decompress.rs:1218-1233) ---------------------------------
+
+def test_fixed_tables_golden(golden_constants):
+    st, litlen, dist, eof = ob.build_decode_tables(288, fixed_code_lengths())
+    assert st == 0
+    assert litlen[:512].tolist() == golden_constants["FIXED_LITLEN_TABLE"]
+    assert dist[:32].tolist() == golden_constants["FIXED_DIST_TABLE"]
+    # the reference replicates the constants 8x / 16x (src/decompress.rs:400-405)
+    assert np.array_equal(litlen, np.tile(litlen[:512], 8))
+    assert np.array_equal(dist, np.tile(dist[:32], 16))
+    # parity trap 1: fixed symbols 286/287 are bare EXCEPTIONAL entries -> end of block
+    assert litlen[99] == 0x4008 and litlen[227] == 0x4008
+
+
+# ---- huffman.rs known-answer tests (src/huffman.rs:335-480) -----------------------------
+
+def _rev(bits, width):
+    return int(format(bits, "0%db" % width)[::-1], 2)
+
+
+class LitlenTables:
+    def __init__(self, lengths):
+        ent = ob.const_array("fdo_litlen_table_entries", 288, np.uint32)
+        ok, self.codes, self.primary, self.secondary = ob.build_table(lengths, ent, 4096, False, True)
+        assert ok
+        self.validate(lengths)
+
+    def validate(self, lengths):
+        # src/huffman.rs:191-250 validate_tables
+        only_double = max(lengths) * 2 <= 12
+        for i, entry in enumerate(self.primary.tolist()):
+            if entry & LITERAL_ENTRY:
+                adv = (entry >> 8) & 0x7F
+                assert adv in (1, 2)
+                if adv == 1:
+                    assert not only_double, "unexpected single literal at %d" % i
+                assert 0 < (entry & 0xFF) <= 15
+            elif entry & SECONDARY_TABLE_ENTRY:
+                mask = entry & 0xFF
+                nbits = bin(mask).count("1")
+                assert nbits > 0 and mask == (1 << nbits) - 1 and nbits + 12 <= 15
+                assert (entry >> 16) + mask <= len(self.secondary)
+            else:
+                assert len(lengths) > 256
+
+    def decode(self, inp):
+        entry = int(self.primary[inp & 0xFFF])
+        if entry & LITERAL_ENTRY:
+            n = (entry & 0xF00) >> 8
+            s1, s2, bits = (entry >> 16) & 0xFF, (entry >> 24) & 0xFF, entry & 0xF
+            return ("single", s1, bits) if n == 1 else ("double", s1, s2, bits)
+        assert entry & SECONDARY_TABLE_ENTRY
+        e2 = int(self.secondary[(entry >> 16) + ((inp >> 12) & (entry & 0xFF))])
+        return ("secondary", e2 >> 4, e2 & 0xF)
+
+
+def test_rfc1951_example1():
+    t = LitlenTables([2, 1, 3, 3])
+    assert t.decode(_rev(0b00000000, 8)) == ("double", 1, 1, 2)
+    assert t.decode(_rev(0b11011000, 8)) == ("double", 2, 2, 6)
+    assert t.decode(_rev(0b11111100, 8)) == ("double", 3, 3, 6)
+    assert t.decode(_rev(0b01000000, 8)) == ("double", 1, 0, 3)
+
+
+def test_rfc1951_example2():
+    t = LitlenTables([3, 3, 3, 3, 3, 2, 4, 4])
+    assert t.decode(_rev(0b01001100, 8)) == ("double", 0, 1, 6)
+    assert t.decode(_rev(0b00000000, 8)) == ("double", 5, 5, 4)
+    assert t.decode(_rev(0b11111110, 8)) == ("double", 7, 6, 8)
+
+
+def test_secondary_table():
+    t = LitlenTables([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 15])
+    assert t.decode(_rev(0b00000000, 8)) == ("double", 0, 0, 2)
+    assert t.decode(_rev(0b11101110, 8)) == ("double", 3, 3, 8)
+    assert t.decode(_rev(0b1111111111111110, 16)) == ("secondary", 15, 15)
+    assert t.decode(_rev(0b1111111111111111, 16)) == ("secondary", 15, 15)
+
+
+def test_incomplete_and_oversubscribed_codes_rejected():
+    ent = ob.const_array("fdo_litlen_table_entries", 288, np.uint32)
+    assert not ob.build_table([1, 2, 3], ent, 4096, False, True)[0]       # incomplete
+    assert not ob.build_table([1, 1, 1], ent, 4096, False, True)[0]       # over-subscribed
+    assert not ob.build_table([1], ent, 4096, False, True)[0]             # single litlen code
+    dent = ob.const_array("fdo_distance_table_entries", 32, np.uint32)
+    ok, _, prim, _ = ob.build_table([0, 1] + [0] * 30, dent, 512, True, False)
+    assert ok and prim[1] == 0 and prim[0] == (int(dent[1]) | 1)           # huffman.rs:45-58
+
+
+# ---- regression vectors (src/decompress.rs:1331-1384) -----------------------------------
+
+@pytest.mark.parametrize("name", ["input-chunking-sensitivity-example1.zz",
+                                  "input-chunking-sensitivity-example2.zz",
+                                  "input-chunking-sensitivity-example3.zz"])
+def test_zz_vectors(golden_dir, golden_manifest, name):
+    data = open(os.path.join(golden_dir, "vectors", name), "rb").read()
+    exp = golden_manifest["zz"][name]
+    whole = ob.decompress_by_chunks(data, 0)
+    bytewise = ob.decompress_by_chunks(data, 1)
+    assert whole == bytewise  # verify_no_sensitivity_to_input_chunking
+    assert whole[0] == exp["status_ignore_adler"]
+    if whole[0] == 0:
+        assert len(whole[1]) == exp["length"]
+        assert zlib.adler32(whole[1]) == exp["adler32"]
+        assert ob.adler32(whole[1]) == exp["adler32"]
+
+
+def test_zz_example1_checksum_is_wrong_unless_ignored(golden_dir):
+    data = open(os.path.join(golden_dir, "vectors", "input-chunking-sensitivity-example1.zz"), "rb").read()
+    st, out, _ = ob.decompress_bounded(data, 1 << 20)
+    assert ob.STATUS_NAMES[st] == "WrongChecksum"
+    st, out, ad = ob.decompress_bounded(data, 1 << 20, ignore_adler32=True)
+    assert st == 0 and len(out) == 281 and ad == 751299
+
+
+def test_corpus_replay(golden_dir, golden_manifest):
+    hdr = bytes(ob.const_array("fdo_ultrafast_header", 54, np.uint8))
+    for name, exp in golden_manifest["corpus"].items():
+        data = open(os.path.join(golden_dir, "vectors", "corpus", name), "rb").read()
+        assert exp["zlib_ok"]
+        st, out, ad = ob.decompress_bounded(data, 1 << 20)
+        assert st == 0, (name, ob.STATUS_NAMES[st])
+        assert len(out) == exp["length"] and ad == exp["adler32"]
+        assert out == zlib.decompress(data)
+        for chunk in (1, 3, 7):
+            st2, out2 = ob.decompress_by_chunks(data, chunk)
+            assert st2 == 0 and out2 == out
+
+
+# ---- stored / checksum / trailer semantics (src/decompress.rs:1261-1325) ----------------
+
+def test_level1_empty_kat_and_zero_length():
+    empty = ob.compress_stored(b"")
+    assert empty == bytes([0x78, 0x01, 0x03, 0x00, 0x00, 0x00, 0x00, 0x01])  # parity trap 11
+    spliced = bytearray(empty)
+    for _ in range(10):
+        spliced[2:2] = bytes([0, 0, 0, 0xFF, 0xFF])
+    d = ob.Decompressor()
+    st, consumed, produced = d.read(bytes(spliced), np.zeros(0, dtype=np.uint8), 0)
+    assert st == 0 and d.is_done() and consumed == len(spliced) and produced == 0
+
+
+def test_ignore_adler32_and_wrong_checksum():
+    comp = bytearray(zlib.compress(b"Hello world!", 1))
+    comp[-1] = (comp[-1] + 1) & 0xFF
+    st, _, _ = ob.decompress_bounded(bytes(comp), 1024)
+    assert ob.STATUS_NAMES[st] == "WrongChecksum"
+    d = ob.Decompressor()
+    d.ignore_adler32()
+    buf = np.zeros(1024, dtype=np.uint8)
+    st, _, produced = d.read(bytes(comp), buf, 0)
+    assert st == 0 and buf[:produced].tobytes() == b"Hello world!"
+
+
+def test_checksum_after_eof():
+    inp = b"Hello world!"
+    comp = zlib.compress(inp, 1)
+    d = ob.Decompressor()
+    buf = np.zeros(1024, dtype=np.uint8)
+    st, consumed, written = d.read(comp[:-1], buf, 0)
+    assert st == 0 and written == len(inp) and consumed == len(comp) - 1
+    st, consumed2, written2 = d.read(comp[consumed:], buf[:written], written)
+    assert st == 0 and d.is_done() and consumed2 == 1 and written2 == 0
+    assert buf[:len(inp)].tobytes() == inp
+
+
+def test_trailing_bytes_ignored_and_truncation():
+    comp = zlib.compress(bytes(range(256)) * 4, 6)
+    st, out, _ = ob.decompress_bounded(comp + b"garbage", 1 << 16)
+    assert st == 0 and out == bytes(range(256)) * 4
+    for cut in range(len(comp)):
+        st, _, _ = ob.decompress_bounded(comp[:cut], 1 << 16)
+        assert ob.STATUS_NAMES[st] in ("InsufficientInput",), (cut, ob.STATUS_NAMES[st])
+
+
+def test_output_too_large():
+    raw = bytes(1000) + bytes(range(200))
+    comp = zlib.compress(raw, 6)
+    st, out, _ = ob.decompress_bounded(comp, len(raw))
+    assert st == 0 and out == raw
+    st, out, _ = ob.decompress_bounded(comp, len(raw) - 1)
+    assert ob.STATUS_NAMES[st] == "OutputTooLarge" and out == raw[:-1]
+    st, out, _ = ob.decompress_bounded(comp, 0)
+    assert ob.STATUS_NAMES[st] == "OutputTooLarge"
+
+
+# ---- differential vs zlib (the role of miniz_oxide in src/decompress.rs:1159-1259) ------
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+@pytest.mark.parametrize("level", [0, 1, 3, 6, 9])
+def test_differential_vs_zlib_levels(level):
+    r = _rng(level)
+    for n in (0, 1, 50, 2048, 50000, 200000):
+        data = (r.integers(0, 256, n, dtype=np.uint8) % 5).astype(np.uint8).tobytes()
+        comp = zlib.compress(data, level)
+        st, out, ad = ob.decompress_bounded(comp, max(n, 1))
+        assert st == 0 and out == data and ad == zlib.adler32(data)
+
+
+def test_differential_fixed_and_constant_and_far_matches():
+    r = _rng(7)
+    cases = [bytes(50), bytes([5]) * 2048, bytes([128]) * 2048, bytes([254]) * 2048]
+    blob = r.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    cases.append(blob + blob[:30000])                       # distance ~40000 > 32768? (no match) 
+    cases.append(blob[:30000] + blob[:30000])               # distance 30000
+    cases.append(bytes(r.integers(0, 4, 100000, dtype=np.uint8)))
+    for data in cases:
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY):
+            c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strategy)
+            comp = c.compress(data) + c.flush()
+            st, out, _ = ob.decompress_bounded(comp, len(data))
+            assert st == 0 and out == data
+            # the reference helper caps at 5000 read() calls (test_utils.rs:66-69)
+            st2, out2 = ob.decompress_by_chunks(comp, len(comp) // 4000 + 1)
+            assert st2 == 0 and out2 == data
+
+
+def test_sync_flush_empty_blocks():
+    c = zlib.compressobj(6)
+    comp = c.compress(b"abc") + c.flush(zlib.Z_SYNC_FLUSH) + c.flush(zlib.Z_FULL_FLUSH)
+    comp += c.compress(b"def" * 100) + c.flush(zlib.Z_SYNC_FLUSH) + c.flush()
+    st, out, _ = ob.decompress_bounded(comp, 4096)
+    assert st == 0 and out == b"abc" + b"def" * 100
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    comp = c.compress(b"") + c.flush(zlib.Z_PARTIAL_FLUSH) + c.flush(zlib.Z_PARTIAL_FLUSH)
+    comp += c.compress(b"xyz") + c.flush()
+    st, out, _ = ob.decompress_bounded(comp, 4096)
+    assert st == 0 and out == b"xyz"
+
+
+# ---- ultra-fast encoder (src/compress/ultrafast.rs:195-224 round trips) -----------------
+
+def test_ultrafast_roundtrips_through_zlib(golden_constants):
+    r = _rng(11)
+    cases = [b"", b"Hello world!", bytes(2048), bytes([5]) * 2048, bytes([128]) * 2048,
+             bytes([254]) * 2048, bytes(65536), bytes(7), bytes(8), bytes(9), bytes(258 + 1),
+             bytes(258 * 3 + 6), b"\x01" + bytes(300) + b"\x02"]
+    for _ in range(10):
+        cases.append(r.integers(0, 256, 2048, dtype=np.uint8).tobytes())
+    for n in (1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1000, 4096, 65536):
+        x = r.integers(0, 256, n, dtype=np.uint8)
+        x[r.random(n) < 0.6] = 0
+        cases.append(x.tobytes())
+    hdr = bytes(golden_constants["ULTRAFAST_HEADER"])
+    for data in cases:
+        comp = ob.compress_ultra_fast(data)
+        assert comp[:53] == hdr[:53]
+        assert zlib.decompress(comp) == data
+        st, out, _ = ob.decompress_bounded(comp, max(len(data), 1))
+        assert st == 0 and out == data
+        assert len(comp) <= ob.lib().fdo_ultrafast_bound(len(data))
+
+
+def test_ultrafast_kats():
+    # SURVEY.md 8c candidate KATs (derived independently in the survey session)
+    assert ob.compress_ultra_fast(b"").hex() == (
+        "7801edc003a0245996c6f1ff77ee8dc8cca7724b63ae6ddbb66ddbb66ddbb66d698c9e964aaf9e323322eef9"
+        "76b76a7aa6873b6bd5ef1f0100000001")
+    hw = ob.compress_ultra_fast(b"Hello world!")
+    assert len(hw) == 77 and hw.hex().endswith("d5ef8d3fe0c33ffca31efc491ff5b11ffefe0ff9471d09045e")
+    z = ob.compress_ultra_fast(bytes(2048))
+    assert len(z) == 71 and z.hex().endswith("d58fabaebaeaaaabaebaeaff9d7f0408000001")
+    assert len(ob.compress_ultra_fast(bytes([5]) * 2048)) == 1596
+
+
+def test_ultrafast_header_decodes_to_huffman_lengths(golden_constants):
+    # decoding HEADER must yield HLIT=286, HDIST=1 and exactly HUFFMAN_LENGTHS: walk the
+    # dynamic header with an independent python reader and compare.
+    comp = ob.compress_ultra_fast(b"")
+    bits = int.from_bytes(comp, "little")
+    pos = 16
+    def take(n):
+        nonlocal pos
+        v = (bits >> pos) & ((1 << n) - 1)
+        pos += n
+        return v
+    assert take(1) == 1 and take(2) == 2
+    hlit, hdist, hclen = take(5) + 257, take(5) + 1, take(4) + 4
+    assert (hlit, hdist) == (286, 1)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl = [0] * 19
+    for i in range(hclen):
+        cl[order[i]] = take(3)
+    # canonical decode of the CL code
+    codes = {}
+    code = 0
+    for ln in range(1, 8):
+        for s in range(19):
+            if cl[s] == ln:
+                codes[(ln, code)] = s
+                code += 1
+        code <<= 1
+    lens = []
+    while len(lens) < hlit + hdist:
+        c, ln = 0, 0
+        while True:
+            c = (c << 1) | take(1)
+            ln += 1
+            if (ln, c) in codes:
+                s = codes[(ln, c)]
+                break
+        if s < 16:
+            lens.append(s)
+        elif s == 16:
+            lens += [lens[-1]] * (3 + take(2))
+        elif s == 17:
+            lens += [0] * (3 + take(3))
+        else:
+            lens += [0] * (11 + take(7))
+    assert lens[:286] == golden_constants["HUFFMAN_LENGTHS"]
+    assert lens[286:] == [1]
+    assert pos == 53 * 8 + 5
