@@ -1,0 +1,16 @@
+"""fdeflate_amd -- MI355X-native batched DEFLATE codec behind fdeflate's PNG-path API.
+
+Public surface mirrors image-rs/fdeflate (reference src/lib.rs:29-36) for the hot path:
+decompress_to_vec, decompress_to_vec_bounded, compress_to_vec_ultra_fast, DecompressionError,
+plus the batched device entry points.  See DESIGN.md / INTEGRATION.md.
+"""
+from .api import (DecompressionError, OutputTooLarge, STATUS_NAMES, FLAG_IGNORE_ADLER32,
+                  FLAG_SERIAL_ONLY, compress_to_vec_ultra_fast, debug_build_tables,
+                  decompress_to_vec, decompress_to_vec_bounded, deflate_ultrafast_batch,
+                  inflate_batch, ultrafast_bound)
+
+__all__ = [
+    "DecompressionError", "OutputTooLarge", "STATUS_NAMES", "FLAG_IGNORE_ADLER32",
+    "FLAG_SERIAL_ONLY", "compress_to_vec_ultra_fast", "debug_build_tables", "decompress_to_vec",
+    "decompress_to_vec_bounded", "deflate_ultrafast_batch", "inflate_batch", "ultrafast_bound",
+]

@@ -1,0 +1,65 @@
+"""ctypes loader for libfdeflate_hip.so (the C ABI of include/fdeflate_hip.h).
+
+There is no fallback: if the shared library has not been built, or no GPU is usable, the
+calls raise.  Build with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C fdeflate_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfdeflate_hip.so")
+
+_lib = None
+
+
+class FdeflateHipError(RuntimeError):
+    """Infrastructure failure reported by the C ABI (not a per-stream decode error)."""
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FdeflateHipError(
+            "%s is missing: the HIP extension has not been built (make -C fdeflate_amd/csrc); "
+            "fdeflate_amd has no CPU fallback" % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, u64, u32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
+    L.fdh_version.restype = u32
+    L.fdh_status_name.restype = C.c_char_p
+    L.fdh_status_name.argtypes = [u32]
+    L.fdh_last_error.restype = C.c_char_p
+    L.fdh_device_count.restype = C.c_int
+    L.fdh_ultrafast_bound.restype = u64
+    L.fdh_ultrafast_bound.argtypes = [u64]
+    L.fdh_inflate_batch.restype = C.c_int
+    L.fdh_inflate_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, u32, vp]
+    L.fdh_deflate_ultrafast_batch.restype = C.c_int
+    L.fdh_deflate_ultrafast_batch.argtypes = [vp, vp, vp, vp, vp, u64, vp]
+    L.fdh_debug_build_tables.restype = C.c_int
+    L.fdh_debug_build_tables.argtypes = [vp, u32, vp, vp, vp, vp]
+    pp = C.POINTER(C.c_void_p)
+    L.fdh_decompress_to_vec.restype = C.c_int
+    L.fdh_decompress_to_vec.argtypes = [vp, sz, pp, C.POINTER(sz), C.POINTER(u32)]
+    L.fdh_decompress_to_vec_bounded.restype = C.c_int
+    L.fdh_decompress_to_vec_bounded.argtypes = [vp, sz, sz, pp, C.POINTER(sz), C.POINTER(u32)]
+    L.fdh_compress_to_vec_ultra_fast.restype = C.c_int
+    L.fdh_compress_to_vec_ultra_fast.argtypes = [vp, sz, pp, C.POINTER(sz)]
+    L.fdh_free.argtypes = [vp]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "fdh_version", "fdh_status_name", "fdh_last_error", "fdh_device_count", "fdh_ultrafast_bound",
+    "fdh_inflate_batch", "fdh_deflate_ultrafast_batch", "fdh_debug_build_tables",
+    "fdh_decompress_to_vec", "fdh_decompress_to_vec_bounded", "fdh_compress_to_vec_ultra_fast",
+    "fdh_free",
+]
+
+
+def check(rc):
+    if rc != 0:
+        raise FdeflateHipError("fdeflate_hip error %d: %s" % (rc, lib().fdh_last_error().decode()))

@@ -1,0 +1,163 @@
+"""Host-side mirror of fdeflate's public API for the PNG path (reference src/lib.rs:29-36),
+implemented over the C ABI (include/fdeflate_hip.h).  Same names, argument meaning and error
+behaviour as the Rust crate:
+
+    decompress_to_vec(input) -> bytes                  raises DecompressionError
+    decompress_to_vec_bounded(input, maxlen) -> bytes  raises DecompressionError / OutputTooLarge
+    compress_to_vec_ultra_fast(input) -> bytes
+
+and the batched entry points the GPU exists for:
+
+    inflate_batch(...), deflate_ultrafast_batch(...)   torch uint8/int64 tensors on the device
+
+torch is used only as the owner of device memory and streams.
+"""
+import ctypes as C
+
+from . import _lib
+
+STATUS_NAMES = [
+    "Ok", "BadZlibHeader", "InsufficientInput", "InvalidBlockType",
+    "InvalidUncompressedBlockLength", "InvalidHlit", "InvalidHdist", "InvalidCodeLengthRepeat",
+    "BadCodeLengthHuffmanTree", "BadLiteralLengthHuffmanTree", "BadDistanceHuffmanTree",
+    "InvalidLiteralLengthCode", "InvalidDistanceCode", "InputStartsWithRun", "DistanceTooFarBack",
+    "WrongChecksum", "ExtraInput", "OutputTooLarge",
+]
+OUTPUT_TOO_LARGE = 17
+FLAG_IGNORE_ADLER32 = 1
+FLAG_SERIAL_ONLY = 2
+
+
+class DecompressionError(Exception):
+    """Mirror of fdeflate::DecompressionError (src/decompress.rs:14-48); `.kind` is the variant."""
+
+    def __init__(self, status):
+        self.status = int(status)
+        self.kind = STATUS_NAMES[self.status] if self.status < len(STATUS_NAMES) else "Unknown"
+        super().__init__(self.kind)
+
+
+class OutputTooLarge(Exception):
+    """Mirror of BoundedDecompressionError::OutputTooLarge (src/decompress.rs:1097-1101)."""
+
+    def __init__(self, partial_output):
+        self.partial_output = partial_output
+        super().__init__("OutputTooLarge")
+
+
+def _take(ptr, n):
+    try:
+        return C.string_at(ptr, n) if n else b""
+    finally:
+        _lib.lib().fdh_free(ptr)
+
+
+def decompress_to_vec_bounded(data, maxlen):
+    """fdeflate::decompress_to_vec_bounded (src/decompress.rs:1111)."""
+    L = _lib.lib()
+    data = bytes(data)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    st = C.c_uint32()
+    _lib.check(L.fdh_decompress_to_vec_bounded(data, len(data), maxlen, C.byref(out), C.byref(n), C.byref(st)))
+    buf = _take(out, n.value)
+    if st.value == 0:
+        return buf
+    if st.value == OUTPUT_TOO_LARGE:
+        raise OutputTooLarge(buf)
+    raise DecompressionError(st.value)
+
+
+def decompress_to_vec(data):
+    """fdeflate::decompress_to_vec (src/decompress.rs:1079)."""
+    L = _lib.lib()
+    data = bytes(data)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    st = C.c_uint32()
+    _lib.check(L.fdh_decompress_to_vec(data, len(data), C.byref(out), C.byref(n), C.byref(st)))
+    buf = _take(out, n.value)
+    if st.value != 0:
+        raise DecompressionError(st.value)
+    return buf
+
+
+def compress_to_vec_ultra_fast(data):
+    """fdeflate::compress_to_vec_ultra_fast (src/compress/mod.rs:313)."""
+    L = _lib.lib()
+    data = bytes(data)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    _lib.check(L.fdh_compress_to_vec_ultra_fast(data, len(data), C.byref(out), C.byref(n)))
+    return _take(out, n.value)
+
+
+def ultrafast_bound(n):
+    return int(_lib.lib().fdh_ultrafast_bound(int(n)))
+
+
+# ------------------------------------------------------------------------------------------
+# batched device entry points
+# ------------------------------------------------------------------------------------------
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check_dev(*ts):
+    import torch
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ValueError("batched entry points take device tensors (HBM resident)")
+        if not t.is_contiguous():
+            raise ValueError("tensors must be contiguous")
+    return torch.cuda.current_stream().cuda_stream
+
+
+def inflate_batch(comp, in_off, out, out_off, out_len=None, status=None, adler=None, flags=0):
+    """One-shot decode of n zlib streams (fdh_inflate_batch).  All tensors on the device:
+    comp/out uint8, in_off/out_off int64 [n+1], out_len/status/adler int32 [n] (allocated when
+    None).  Enqueued on torch's current stream; returns (out_len, status, adler)."""
+    import torch
+    n = in_off.numel() - 1
+    dev = comp.device
+    if out_len is None:
+        out_len = torch.empty(n, dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.empty(n, dtype=torch.int32, device=dev)
+    if adler is None:
+        adler = torch.empty(n, dtype=torch.int32, device=dev)
+    stream = _check_dev(comp, in_off, out, out_off, out_len, status, adler)
+    _lib.check(_lib.lib().fdh_inflate_batch(_ptr(comp), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                           _ptr(out_len), _ptr(status), _ptr(adler), n, flags,
+                                           C.c_void_p(stream)))
+    return out_len, status, adler
+
+
+def deflate_ultrafast_batch(raw, in_off, out, out_off, out_len=None):
+    """Ultra-fast encode of n buffers (fdh_deflate_ultrafast_batch); returns out_len (int32)."""
+    import torch
+    n = in_off.numel() - 1
+    if out_len is None:
+        out_len = torch.empty(n, dtype=torch.int32, device=raw.device)
+    stream = _check_dev(raw, in_off, out, out_off, out_len)
+    _lib.check(_lib.lib().fdh_deflate_ultrafast_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                                     _ptr(out_len), n, C.c_void_p(stream)))
+    return out_len
+
+
+def debug_build_tables(code_lengths, hlit):
+    """Device Huffman-table builder on one set of 320 code lengths -> (status, litlen, dist, eof)."""
+    import torch
+    cl = torch.as_tensor(list(code_lengths), dtype=torch.uint8).cuda()
+    lit = torch.empty(4096, dtype=torch.int32, device="cuda")
+    dist = torch.empty(512, dtype=torch.int32, device="cuda")
+    st = torch.zeros(4, dtype=torch.int32, device="cuda")
+    stream = _check_dev(cl, lit, dist, st)
+    _lib.check(_lib.lib().fdh_debug_build_tables(_ptr(cl), hlit, _ptr(lit), _ptr(dist), _ptr(st),
+                                                C.c_void_p(stream)))
+    torch.cuda.synchronize()
+    s = st.cpu().tolist()
+    return s[0], lit.cpu().numpy().view("uint32"), dist.cpu().numpy().view("uint32"), tuple(s[1:])

@@ -1,0 +1,382 @@
+// deflate_ultrafast.hip -- batched ultra-fast (RLE-of-zeros, fixed Huffman table) zlib encoder.
+//
+// Restates UltraFastCompressor (reference src/compress/ultrafast.rs:9-182) for one wavefront
+// per input buffer.  The reference walks 8-byte chunks with a scalar `run` counter; here one
+// lane owns one chunk of a 64-chunk (512 B) tile and the serial state is recovered with
+// ballots:
+//
+//   * hz(c)  = zero bytes at the high end of chunk c (8 for an all-zero chunk)
+//   * a run is pending at chunk c iff hz(c-1) > 0                      (ultrafast.rs:102-132)
+//   * a non-zero chunk with a pending run closes it with its low zero bytes (`run_extra`,
+//     :105-108) and emits literals for bytes [run_extra, 8 - lz) (:110-119); without a pending
+//     run it emits bytes [0, 8 - lz) (:122-152) -- low zero bytes are then plain literals;
+//   * the run that closes at lane j is  lz(b) + 8 * (j - b - 1) + tz(j)  with b the previous
+//     non-zero chunk (or the carry from earlier tiles).
+//
+// Per-lane bit counts are prefix-summed over the wavefront and every lane ORs its code bits into
+// a zeroed LDS bit ring at its own offset; complete 16-B lines are stored coalesced.  The
+// emitted byte stream is independent of the reference's 64-bit flush granularity
+// (ultrafast.rs:16-29), so bit-exactness only depends on the symbol sequence and the codes.
+#include "device_common.h"
+
+namespace fdh {
+
+// ---- constants: reference data (src/tables.rs:7-20, src/compress/ultrafast.rs:82-86) ----
+struct UfTables {
+    uint32_t sym[286];  // code | len << 16, code bit-reversed as written to the stream
+};
+
+#include "uf_table_data.inc"
+
+// compute_codes (reference src/lib.rs:103-127), evaluated at compile time like the reference's
+// `const HUFFMAN_CODES` (src/tables.rs:22-25).
+constexpr UfTables make_uf_tables() {
+    UfTables t{};
+    uint32_t code = 0;
+    for (unsigned len = 1; len <= 16; len++) {
+        for (int i = 0; i < 286; i++) {
+            if (kHuffmanLengths[i] == len) {
+                uint32_t rev = 0;
+                for (unsigned b = 0; b < len; b++) rev |= ((code >> b) & 1u) << (len - 1 - b);
+                t.sym[i] = rev | ((uint32_t)len << 16);
+                code++;
+            }
+        }
+        code <<= 1;
+    }
+    return t;
+}
+__device__ static const UfTables kUfTables = make_uf_tables();
+static_assert(make_uf_tables().sym[0] == (0u | (2u << 16)), "HUFFMAN_CODES[0] must be 0 (ultrafast.rs:62)");
+
+__device__ static const uint8_t kUfHeader[56] = {
+    kUfHeaderData[0],  kUfHeaderData[1],  kUfHeaderData[2],  kUfHeaderData[3],  kUfHeaderData[4],  kUfHeaderData[5],  kUfHeaderData[6],
+    kUfHeaderData[7],  kUfHeaderData[8],  kUfHeaderData[9],  kUfHeaderData[10], kUfHeaderData[11], kUfHeaderData[12], kUfHeaderData[13],
+    kUfHeaderData[14], kUfHeaderData[15], kUfHeaderData[16], kUfHeaderData[17], kUfHeaderData[18], kUfHeaderData[19], kUfHeaderData[20],
+    kUfHeaderData[21], kUfHeaderData[22], kUfHeaderData[23], kUfHeaderData[24], kUfHeaderData[25], kUfHeaderData[26], kUfHeaderData[27],
+    kUfHeaderData[28], kUfHeaderData[29], kUfHeaderData[30], kUfHeaderData[31], kUfHeaderData[32], kUfHeaderData[33], kUfHeaderData[34],
+    kUfHeaderData[35], kUfHeaderData[36], kUfHeaderData[37], kUfHeaderData[38], kUfHeaderData[39], kUfHeaderData[40], kUfHeaderData[41],
+    kUfHeaderData[42], kUfHeaderData[43], kUfHeaderData[44], kUfHeaderData[45], kUfHeaderData[46], kUfHeaderData[47], kUfHeaderData[48],
+    kUfHeaderData[49], kUfHeaderData[50], kUfHeaderData[51], kUfHeaderData[52], kUfHeaderData[53], 0, 0};
+constexpr uint32_t kUfHeaderBits = 53 * 8 + 5;  // ultrafast.rs:87-88
+
+constexpr int kEncWaves = 4;             // wavefronts (= streams) per workgroup
+constexpr int kEncRingDw = 2048;         // 8 KiB bit ring per wavefront
+constexpr uint32_t kEncRingBits = kEncRingDw * 32;
+constexpr uint32_t kEncTileBudget = kEncRingBits - 1024;
+
+struct EncLds {
+    uint32_t tab[288];
+    uint32_t ring[kEncWaves][kEncRingDw];
+};
+
+struct Encoder {
+    uint32_t* ring;
+    const uint32_t* tab;
+    int lane;
+    uint8_t* out_al;   // slot base rounded down to 16 B
+    uint32_t gmis;     // slot base & 15
+    uint64_t cap_bits; // capacity in q-space bits (gmis*8 + cap*8)
+    uint64_t qbits;    // bits emitted so far incl. the gmis*8 offset (uniform)
+    uint64_t qflushed; // q-space bit position up to which lines are stored (multiple of 128)
+    bool overflow;
+
+    __device__ void or_bits(uint64_t pos, uint32_t bits) {  // bits < 2^32, any lane
+        uint32_t sh = (uint32_t)pos & 31;
+        uint64_t v = (uint64_t)bits << sh;
+        uint32_t d = (uint32_t)(pos >> 5);
+        if ((uint32_t)v) atomicOr(&ring[d & (kEncRingDw - 1)], (uint32_t)v);
+        if ((uint32_t)(v >> 32)) atomicOr(&ring[(d + 1) & (kEncRingDw - 1)], (uint32_t)(v >> 32));
+    }
+
+    // Store every complete 16-B line (all lines when final) and re-zero it in the ring.
+    __device__ void flush(bool final) {
+        wave_sync();
+        uint64_t end_line = final ? (qbits + 127) >> 7 : qbits >> 7;
+        uint64_t line0 = qflushed >> 7;
+        uint64_t end_byte = (qbits + 7) >> 3;  // q-space byte just past the data
+        for (uint64_t ln = line0 + lane; ln < end_line; ln += kWave) {
+            uint32_t di = (uint32_t)(ln * 4) & (kEncRingDw - 1);
+            uint4 v = *reinterpret_cast<uint4*>(&ring[di]);
+            *reinterpret_cast<uint4*>(&ring[di]) = make_uint4(0, 0, 0, 0);
+            uint64_t b0 = ln * 16;
+            uint64_t lo = (b0 < gmis) ? gmis - b0 : 0;
+            uint64_t hi = (b0 + 16 > end_byte) ? end_byte - b0 : 16;
+            if (overflow || b0 + hi > (cap_bits >> 3)) {
+                overflow = true;  // slot too small: never write past it
+            } else if (lo == 0 && hi == 16) {
+                *reinterpret_cast<uint4*>(out_al + b0) = v;
+            } else {
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if ((uint64_t)j >= lo && (uint64_t)j < hi) out_al[b0 + j] = (uint8_t)(w[j >> 2] >> ((j & 3) * 8));
+                }
+            }
+        }
+        overflow = __any(overflow);
+        if (end_line > line0) qflushed = end_line << 7;
+        wave_sync();
+    }
+
+    // uniform emission of up to 32 bits by lane 0 (header, EOB, trailer, slow paths)
+    __device__ void emit_uniform(uint32_t bits, uint32_t nbits) {
+        if (qbits + nbits - qflushed > kEncTileBudget) flush(false);
+        if (lane == 0) or_bits(qbits, bits);
+        qbits += nbits;
+    }
+
+    // write_run (ultrafast.rs:45-67) for one run, emitted by the whole wavefront (slow path
+    // and the end-of-data run).
+    __device__ void emit_run_uniform(uint32_t run) {
+        emit_uniform(0, 2);  // literal 0
+        run -= 1;
+        uint32_t nrep = run / 258, r = run % 258;
+        uint32_t e285 = tab[285];
+        uint32_t rep_bits = e285 & 0xFFFF, rep_n = (e285 >> 16) + 1;
+        while (nrep > 0) {
+            uint32_t m = min(nrep, (uint32_t)kWave);
+            if (qbits + (uint64_t)m * rep_n - qflushed > kEncTileBudget) flush(false);
+            if ((uint32_t)lane < m) or_bits(qbits + (uint64_t)lane * rep_n, rep_bits);
+            qbits += (uint64_t)m * rep_n;
+            nrep -= m;
+        }
+        uint32_t tb, tn;
+        run_tail(r, tb, tn);
+        emit_uniform(tb, tn);
+    }
+
+    // tail of a run: r = (run - 1) % 258 more zeros (ultrafast.rs:54-64)
+    __device__ void run_tail(uint32_t r, uint32_t& bits, uint32_t& nbits) const {
+        if (r > 4) {
+            uint32_t lp = r - 3, sym, ebits;
+            if (r == 258) {  // unreachable (r < 258), kept for the table's sake
+                sym = 285;
+                ebits = 0;
+            } else if (lp < 8) {
+                sym = 257 + lp;
+                ebits = 0;
+            } else {
+                ebits = (31 - __clz(lp)) - 2;
+                sym = 257 + 4 * ebits + 4 + ((lp >> ebits) & 3);
+            }
+            uint32_t e = tab[sym];
+            uint32_t clen = e >> 16;
+            bits = (e & 0xFFFF) | ((lp & ((1u << ebits) - 1)) << clen);
+            nbits = clen + ebits + 1;  // + the 1-bit distance code (value 0), ultrafast.rs:60
+        } else {
+            bits = 0;
+            nbits = r * 2;  // r literal zeros, HUFFMAN_CODES[0] == 0 (ultrafast.rs:62-63)
+        }
+    }
+};
+
+struct DeflateBatchArgs {
+    const uint8_t* in;
+    const uint64_t* in_off;
+    uint8_t* out;
+    const uint64_t* out_off;
+    uint32_t* out_len;
+    uint64_t n;
+};
+
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t& total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        uint32_t y = __shfl_up(x, o, kWave);
+        if (lane >= o) x += y;
+    }
+    total = __shfl(x, kWave - 1, kWave);
+    return x - v;
+}
+
+__global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(DeflateBatchArgs a) {
+    __shared__ EncLds lds;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x / kWave;
+    for (int i = threadIdx.x; i < 288; i += kEncWaves * kWave) lds.tab[i] = i < 286 ? kUfTables.sym[i] : 0;
+    for (int i = lane; i < kEncRingDw; i += kWave) lds.ring[wid][i] = 0;
+    __syncthreads();
+    const uint64_t sid = (uint64_t)blockIdx.x * kEncWaves + wid;
+    if (sid >= a.n) return;
+
+    const uint8_t* in = a.in + a.in_off[sid];
+    const uint64_t len = a.in_off[sid + 1] - a.in_off[sid];
+    uint8_t* out = a.out + a.out_off[sid];
+    const uint64_t cap = a.out_off[sid + 1] - a.out_off[sid];
+
+    Encoder enc;
+    enc.ring = lds.ring[wid];
+    enc.tab = lds.tab;
+    enc.lane = lane;
+    enc.gmis = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15);
+    enc.out_al = out - enc.gmis;
+    enc.cap_bits = ((uint64_t)enc.gmis + cap) * 8;
+    enc.qbits = (uint64_t)enc.gmis * 8;
+    enc.qflushed = 0;
+    enc.overflow = false;
+
+    // ---- header: 53 bytes + 5 bits (ultrafast.rs:81-91) ----
+    if (lane < 14) {
+        uint32_t w = (uint32_t)kUfHeader[lane * 4] | ((uint32_t)kUfHeader[lane * 4 + 1] << 8) |
+                     ((uint32_t)kUfHeader[lane * 4 + 2] << 16) | ((uint32_t)kUfHeader[lane * 4 + 3] << 24);
+        if (lane == 13) w &= (1u << (kUfHeaderBits - 13 * 32)) - 1;
+        enc.or_bits(enc.qbits + (uint64_t)lane * 32, w);
+    }
+    enc.qbits += kUfHeaderBits;
+
+    // ---- Adler-32 of the input (ultrafast.rs:95), per-lane partial sums ----
+    // A = 1 + sum d_i ; B = len + sum (len - i) d_i  (mod 65521)
+    uint64_t acc_a = 0, acc_b = 0;
+
+    const uint64_t nchunks = len / 8;
+    uint32_t carry = 0;  // pending run (zero bytes) entering the tile; may exceed 2^32? len < 2^32 assumed below
+    for (uint64_t t0 = 0; t0 < nchunks; t0 += kWave) {
+        const uint64_t c = t0 + lane;
+        const bool valid = c < nchunks;
+        uint64_t x = 0;
+        if (valid) x = *reinterpret_cast<const uint64_t*>(in + c * 8);  // HW handles misalignment
+        const uint32_t nvalid = (uint32_t)min((uint64_t)kWave, nchunks - t0);
+        {   // adler partials: weight of byte j of this chunk is len - (c*8 + j)
+            uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+            uint32_t s = bytesum4(xl) + bytesum4(xh);
+            uint32_t u = bytedot4(xl, 0x03020100u, 0);
+            u = bytedot4(xh, 0x07060504u, u);
+            acc_a += s;
+            acc_b += (uint64_t)(len - c * 8) * s - u;  // valid lanes only contribute (x = 0 otherwise)
+        }
+        const bool nz = valid && x != 0;
+        const uint32_t tzb = nz ? (uint32_t)__builtin_ctzll(x) >> 3 : 0;
+        const uint32_t lzb = nz ? (uint32_t)__builtin_clzll(x) >> 3 : 0;
+        const uint64_t nzmask = __ballot(nz);
+        const uint64_t below = nzmask & lanemask_lt(lane);
+        const int b = below ? 63 - __clzll((long long)below) : -1;
+        const uint32_t lz_b = __shfl(lzb, b < 0 ? 0 : b, kWave);
+        const uint32_t P = b >= 0 ? lz_b + 8u * (uint32_t)(lane - b - 1) : carry + 8u * (uint32_t)lane;
+        const bool pend = nz && P > 0;
+        const uint32_t lo = pend ? tzb : 0, hi = 8 - lzb;
+        // ---- literals of bytes [lo, hi): four 2-byte pieces (<= 24 bits each) ----
+        uint32_t pb[4], pn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t j0 = 2 * k, j1 = 2 * k + 1;
+            uint32_t e0 = lds.tab[(uint32_t)(x >> (8 * j0)) & 0xFF];
+            uint32_t e1 = lds.tab[(uint32_t)(x >> (8 * j1)) & 0xFF];
+            bool u0 = nz && j0 >= lo && j0 < hi, u1 = nz && j1 >= lo && j1 < hi;
+            uint32_t n0 = u0 ? e0 >> 16 : 0, n1 = u1 ? e1 >> 16 : 0;
+            uint32_t c0 = u0 ? e0 & 0xFFFF : 0, c1 = u1 ? e1 & 0xFFFF : 0;
+            pb[k] = c0 | (c1 << n0);
+            pn[k] = n0 + n1;
+        }
+        // ---- run closed by this chunk (write_run, ultrafast.rs:45-67) ----
+        uint32_t nrep = 0, tail_bits = 0, tail_n = 0, run_n = 0;
+        if (pend) {
+            uint32_t run = P + tzb - 1;  // after the leading literal 0
+            nrep = run / 258;
+            enc.run_tail(run % 258, tail_bits, tail_n);
+            run_n = 2 + nrep * ((lds.tab[285] >> 16) + 1) + tail_n;
+        }
+        const uint32_t e285 = lds.tab[285];
+        const uint32_t lane_bits = run_n + pn[0] + pn[1] + pn[2] + pn[3];
+        uint32_t total;
+        const uint32_t off = wave_excl_scan_u32(lane_bits, lane, total);
+        if ((uint64_t)total + (enc.qbits - enc.qflushed) > kEncTileBudget) {
+            enc.flush(false);
+        }
+        if ((uint64_t)total + (enc.qbits - enc.qflushed) > kEncTileBudget) {
+            // ---- slow path: a run too long for the ring; lanes take turns ----
+            for (int l = 0; l < (int)nvalid; l++) {
+                bool p_l = __shfl((int)pend, l, kWave) != 0;
+                uint32_t P_l = __shfl(P, l, kWave), tz_l = __shfl(tzb, l, kWave);
+                if (p_l) enc.emit_run_uniform(P_l + tz_l);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t bits = __shfl(pb[k], l, kWave), nb = __shfl(pn[k], l, kWave);
+                    enc.emit_uniform(bits, nb);
+                }
+            }
+        } else {
+            uint64_t pos = enc.qbits + off;
+            if (pend) {
+                pos += 2;
+                uint32_t rep_bits = e285 & 0xFFFF;
+                const uint32_t rep_n = (e285 >> 16) + 1;  // + the 1-bit distance code, ultrafast.rs:50
+                for (uint32_t i = 0; i < nrep; i++) {
+                    enc.or_bits(pos, rep_bits);
+                    pos += rep_n;
+                }
+                enc.or_bits(pos, tail_bits);
+                pos += tail_n;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                enc.or_bits(pos, pb[k]);
+                pos += pn[k];
+            }
+            enc.qbits += total;
+        }
+        // ---- carry: pending run after this tile ----
+        if (nzmask) {
+            int last = 63 - __clzll((long long)nzmask);
+            carry = __shfl(lzb, last, kWave) + 8u * (nvalid - 1 - (uint32_t)last);
+        } else {
+            carry += 8u * nvalid;
+        }
+        if (enc.qbits - enc.qflushed > kEncRingBits / 2) enc.flush(false);
+        if (((t0 >> 6) & 0xFFF) == 0xFFF) {  // keep the 64-bit Adler partials far from overflow
+            acc_a %= kAdlerMod;
+            acc_b %= kAdlerMod;
+        }
+    }
+    // ---- pending run at the end of the chunked part (ultrafast.rs:155-157) ----
+    if (carry > 0) enc.emit_run_uniform(carry);
+    // ---- remainder bytes as literals (ultrafast.rs:159-164) ----
+    {
+        const uint32_t rem = (uint32_t)(len & 7);
+        uint32_t bits = 0, nb = 0;
+        if ((uint32_t)lane < rem) {
+            uint32_t bv = in[nchunks * 8 + lane];
+            uint32_t e = lds.tab[bv];
+            bits = e & 0xFFFF;
+            nb = e >> 16;
+            acc_a += bv;
+            acc_b += (uint64_t)(len - (nchunks * 8 + lane)) * bv;
+        }
+        uint32_t total;
+        uint32_t off = wave_excl_scan_u32(nb, lane, total);
+        if ((uint64_t)total + (enc.qbits - enc.qflushed) > kEncTileBudget) enc.flush(false);
+        enc.or_bits(enc.qbits + off, bits);
+        enc.qbits += total;
+    }
+    // ---- finish: EOB, pad to a byte, Adler-32 big-endian (ultrafast.rs:170-181) ----
+    {
+        uint32_t e = lds.tab[256];
+        enc.emit_uniform(e & 0xFFFF, e >> 16);
+        uint32_t pad = (uint32_t)(8 - (enc.qbits & 7)) & 7;
+        enc.emit_uniform(0, pad);
+        // reduce the per-lane Adler partials
+        uint32_t pa = (uint32_t)(acc_a % kAdlerMod), pbm = (uint32_t)(acc_b % kAdlerMod);
+        uint32_t A = (1u + wave_sum_u32(pa)) % kAdlerMod;
+        uint32_t B = (uint32_t)(((len % kAdlerMod) + wave_sum_u32(pbm)) % kAdlerMod);
+        uint32_t adler = (B << 16) | A;
+        enc.emit_uniform(__builtin_bswap32(adler), 32);
+    }
+    enc.flush(true);
+    if (lane == 0) {
+        uint64_t out_bytes = (enc.qbits >> 3) - enc.gmis;
+        a.out_len[sid] = enc.overflow ? 0xFFFFFFFFu : (uint32_t)out_bytes;
+    }
+}
+
+}  // namespace fdh
+
+extern "C" int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
+                                            const uint64_t* out_off, uint32_t* out_len, uint64_t n,
+                                            hipStream_t stream) {
+    fdh::DeflateBatchArgs a{in, in_off, out, out_off, out_len, n};
+    if (n == 0) return 0;
+    unsigned blocks = (unsigned)((n + fdh::kEncWaves - 1) / fdh::kEncWaves);
+    hipLaunchKernelGGL(fdh::deflate_ultrafast_kernel, dim3(blocks), dim3(fdh::kEncWaves * fdh::kWave), 0, stream, a);
+    return (int)hipGetLastError();
+}

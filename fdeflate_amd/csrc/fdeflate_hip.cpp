@@ -1,0 +1,197 @@
+// fdeflate_hip.cpp -- host side of the C ABI declared in include/fdeflate_hip.h.
+// Thin: argument checks, kernel launches, and H2D/D2H staging for the single-buffer
+// conveniences.  There is deliberately no CPU decode/encode path in this library.
+#include "../../include/fdeflate_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+extern "C" {
+int fdh_launch_inflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                               uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
+                               hipStream_t stream);
+int fdh_launch_build_tables_debug(const uint8_t* code_lengths, uint32_t hlit, uint32_t* litlen, uint32_t* dist,
+                                  uint32_t* build_status, hipStream_t stream);
+int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                                 uint32_t* out_len, uint64_t n, hipStream_t stream);
+}
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(e == hipErrorOutOfMemory ? FDH_ERR_OUT_OF_MEMORY : FDH_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+bool have_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return false;
+    return n > 0;
+}
+
+const char* kStatusNames[] = {
+    "Ok", "BadZlibHeader", "InsufficientInput", "InvalidBlockType", "InvalidUncompressedBlockLength",
+    "InvalidHlit", "InvalidHdist", "InvalidCodeLengthRepeat", "BadCodeLengthHuffmanTree",
+    "BadLiteralLengthHuffmanTree", "BadDistanceHuffmanTree", "InvalidLiteralLengthCode",
+    "InvalidDistanceCode", "InputStartsWithRun", "DistanceTooFarBack", "WrongChecksum", "ExtraInput",
+    "OutputTooLarge"};
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+uint32_t fdh_version(void) { return FDH_VERSION; }
+
+const char* fdh_status_name(uint32_t s) { return s < 18 ? kStatusNames[s] : "Unknown"; }
+
+const char* fdh_last_error(void) { return g_last_error.c_str(); }
+
+int fdh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint64_t fdh_ultrafast_bound(uint64_t len) { return 53 + (5 + 12 * len + 12 + 7) / 8 + 4; }
+
+int fdh_inflate_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                      uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
+                      void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    if (!in_off || !out_off || !out_len || !status) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
+    if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many streams in one call (max 2^31-1)");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    int rc = fdh_launch_inflate_general(in, in_off, out, out_off, out_len, status, adler, n, flags,
+                                        static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "inflate kernel launch");
+    return FDH_SUCCESS;
+}
+
+int fdh_deflate_ultrafast_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                                uint32_t* out_len, uint64_t n, void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    if (!in_off || !out_off || !out_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
+    if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many buffers in one call (max 2^31-1)");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    int rc = fdh_launch_deflate_ultrafast(in, in_off, out, out_off, out_len, n, static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "deflate kernel launch");
+    return FDH_SUCCESS;
+}
+
+int fdh_debug_build_tables(const uint8_t* code_lengths320, uint32_t hlit, uint32_t* litlen4096, uint32_t* dist512,
+                           uint32_t* build_status, void* hip_stream) {
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    int rc = fdh_launch_build_tables_debug(code_lengths320, hlit, litlen4096, dist512, build_status,
+                                           static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "table-build kernel launch");
+    return FDH_SUCCESS;
+}
+
+// ---- single-buffer conveniences (host memory) --------------------------------------------
+
+static int inflate_one(const uint8_t* input, size_t input_len, size_t cap, uint8_t** output, size_t* output_len,
+                       uint32_t* stream_status) {
+    if (!output || !output_len || !stream_status) return fail(FDH_ERR_INVALID_ARGUMENT, "null result pointer");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    if (cap > 0xFFFFFFFFull) cap = 0xFFFFFFFFull;
+    DevBuf d_in, d_out, d_meta;
+    HIP_TRY(d_in.alloc(input_len));
+    HIP_TRY(d_out.alloc(cap));
+    HIP_TRY(d_meta.alloc(64));
+    uint64_t meta[8] = {0, (uint64_t)input_len, 0, (uint64_t)cap, 0, 0, 0, 0};
+    if (input_len) HIP_TRY(hipMemcpy(d_in.p, input, input_len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
+    uint64_t* m = d_meta.as<uint64_t>();
+    uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
+    int rc = fdh_inflate_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, res + 1, res + 2, 1, 0, nullptr);
+    if (rc != FDH_SUCCESS) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t host_res[4];
+    HIP_TRY(hipMemcpy(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost));
+    *stream_status = host_res[1];
+    size_t n = host_res[0];
+    *output = static_cast<uint8_t*>(std::malloc(n ? n : 1));
+    if (!*output) return fail(FDH_ERR_OUT_OF_MEMORY, "malloc");
+    if (n) HIP_TRY(hipMemcpy(*output, d_out.p, n, hipMemcpyDeviceToHost));
+    *output_len = n;
+    return FDH_SUCCESS;
+}
+
+int fdh_decompress_to_vec_bounded(const uint8_t* input, size_t input_len, size_t maxlen, uint8_t** output,
+                                  size_t* output_len, uint32_t* stream_status) {
+    return inflate_one(input, input_len, maxlen, output, output_len, stream_status);
+}
+
+// decompress_to_vec grows its Vec without bound (src/decompress.rs:1079-1087).  The device needs
+// a slot size up front, so the slot starts at 4x the input (>= 64 KiB) and is doubled while the
+// stream reports OutputTooLarge.
+int fdh_decompress_to_vec(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len,
+                          uint32_t* stream_status) {
+    size_t cap = input_len * 4 + 65536;
+    for (;;) {
+        int rc = inflate_one(input, input_len, cap, output, output_len, stream_status);
+        if (rc != FDH_SUCCESS) return rc;
+        if (*stream_status != FDH_OUTPUT_TOO_LARGE || cap >= 0xFFFFFFFFull) return FDH_SUCCESS;
+        std::free(*output);
+        *output = nullptr;
+        cap = cap * 4 > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap * 4;
+    }
+}
+
+int fdh_compress_to_vec_ultra_fast(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+    if (!output || !output_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null result pointer");
+    if (input_len >= 0xFFFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "buffer too large (>= 4 GiB)");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    size_t cap = (size_t)fdh_ultrafast_bound(input_len);
+    DevBuf d_in, d_out, d_meta;
+    HIP_TRY(d_in.alloc(input_len));
+    HIP_TRY(d_out.alloc(cap));
+    HIP_TRY(d_meta.alloc(64));
+    uint64_t meta[8] = {0, (uint64_t)input_len, 0, (uint64_t)cap, 0, 0, 0, 0};
+    if (input_len) HIP_TRY(hipMemcpy(d_in.p, input, input_len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
+    uint64_t* m = d_meta.as<uint64_t>();
+    uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
+    int rc = fdh_deflate_ultrafast_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr);
+    if (rc != FDH_SUCCESS) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t n32 = 0;
+    HIP_TRY(hipMemcpy(&n32, res, 4, hipMemcpyDeviceToHost));
+    if (n32 == 0xFFFFFFFFu) return fail(FDH_ERR_HIP, "internal: ultra-fast bound exceeded");
+    *output = static_cast<uint8_t*>(std::malloc(n32 ? n32 : 1));
+    if (!*output) return fail(FDH_ERR_OUT_OF_MEMORY, "malloc");
+    HIP_TRY(hipMemcpy(*output, d_out.p, n32, hipMemcpyDeviceToHost));
+    *output_len = n32;
+    return FDH_SUCCESS;
+}
+
+void fdh_free(void* p) { std::free(p); }
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// inflate_tables.h -- wave-parallel Huffman decode-table construction.
+//
+// Restates huffman::build_table (reference src/huffman.rs:18-184) and
+// CompressedBlock::build_tables (reference src/decompress.rs:561-606) for one wavefront.
+// The *decoding function* is identical to the reference's; the entry layout is the device's
+// own (DESIGN.md "decode tables"):
+//
+//   litlen entry (u32), primary index = low kLitBits stream bits
+//     [3:0]   nbits   total bits consumed by the entry (1..15)
+//     [7:4]   kind    K_LIT1 | K_LIT2 | K_LEN | K_EOB | K_LONG
+//     K_LIT1  [15:8] symbol                      [27:24] = nbits
+//     K_LIT2  [15:8] first, [23:16] second,      [27:24] = bits of the first symbol
+//     K_LEN   [12:8] extra-bit count, [31:16] length base
+//     K_LONG  code longer than kLitBits: resolved by a canonical walk (long_decode)
+//   dist entry (u32), primary index = low kDistBits bits
+//     [3:0] nbits, [7:4] kind D_INVALID | D_DIST | D_LONG, [11:8] extra bits, [31:16] base
+//   code-length-code entry (u32): [3:0] nbits, [15:8] symbol
+//
+// Double-literal entries are synthesised exactly where the reference does
+// (src/huffman.rs:110-130): both symbols < 256 and len1 + len2 <= kLitBits.
+#pragma once
+#include "device_common.h"
+
+namespace fdh {
+
+constexpr int kLitBits = 12;
+constexpr int kLitSize = 1 << kLitBits;
+constexpr int kDistBits = 9;
+constexpr int kDistSize = 1 << kDistBits;
+constexpr int kClBits = 7;
+constexpr int kClSize = 1 << kClBits;
+
+enum : uint32_t { K_LIT1 = 0, K_LIT2 = 1, K_LEN = 2, K_EOB = 3, K_LONG = 4 };
+enum : uint32_t { D_INVALID = 0, D_DIST = 1, D_LONG = 2 };
+
+// Canonical-code bookkeeping kept next to a table for long-code walks.
+struct CodeBook {
+    uint32_t hist[16];   // symbols per code length (hist[0] unused, kept 0)
+    uint32_t first[16];  // first canonical code of each length (MSB-first)
+    uint32_t offs[16];   // index of the first symbol of each length in `sorted`
+    uint32_t run[16];    // scratch: symbols of each length placed so far
+};
+
+struct LitlenTraits {
+    static constexpr int kBits = kLitBits;
+    __device__ static uint32_t entry(uint32_t sym, uint32_t nb) {
+        if (sym < 256) return nb | (K_LIT1 << 4) | (sym << 8) | (nb << 24);
+        if (sym == 256 || sym >= 286) return nb | (K_EOB << 4);  // 286/287: parity trap 1
+        return nb | (K_LEN << 4) | ((uint32_t)kLenExtra[sym - 257] << 8) |
+               ((uint32_t)kLenBase[sym - 257] << 16);
+    }
+    __device__ static uint32_t long_entry() { return K_LONG << 4; }
+};
+struct DistTraits {
+    static constexpr int kBits = kDistBits;
+    __device__ static uint32_t entry(uint32_t sym, uint32_t nb) {
+        if (sym >= 30) return nb | (D_INVALID << 4);  // tables.rs:130-140: slots 30,31 are 0
+        return nb | (D_DIST << 4) | ((uint32_t)kDistExtra[sym] << 8) | ((uint32_t)kDistBase[sym] << 16);
+    }
+    __device__ static uint32_t long_entry() { return D_LONG << 4; }
+};
+struct ClTraits {
+    static constexpr int kBits = kClBits;
+    __device__ static uint32_t entry(uint32_t sym, uint32_t nb) { return nb | (sym << 8); }
+    __device__ static uint32_t long_entry() { return 0; }
+};
+
+enum BuildResult : int { BUILD_OK = 0, BUILD_INCOMPLETE = 1 };
+
+// Builds `table` (1 << Traits::kBits entries, LDS) from `lens[0..n)` (LDS).  All 64 lanes call.
+// IS_DIST adds the two distance-only cases of src/huffman.rs:40-59.
+template <class Traits, bool IS_DIST>
+__device__ int build_table(uint32_t* table, const uint8_t* lens, int n, CodeBook& cb,
+                           uint16_t* sorted, int lane) {
+    constexpr int PB = Traits::kBits;
+    constexpr int TSIZE = 1 << PB;
+    if (lane < 16) {
+        cb.hist[lane] = 0;
+        cb.run[lane] = 0;
+    }
+    wave_sync();
+    for (int s = lane; s < n; s += kWave) {
+        uint32_t l = lens[s];
+        if (l) atomicAdd(&cb.hist[l], 1u);
+    }
+    wave_sync();
+    // Kraft sum, maximum length, first codes and sorted offsets (uniform, every lane).
+    uint32_t kraft = 0, nsyms = 0, max_len = 0, code = 0, off = 0, prev = 0;
+    for (int l = 1; l <= 15; l++) {
+        uint32_t h = uni(cb.hist[l]);
+        kraft += h << (15 - l);
+        nsyms += h;
+        if (h) max_len = l;
+        code = (code + prev) << 1;
+        if (lane == 0) {
+            cb.first[l] = code;
+            cb.offs[l] = off;
+        }
+        off += h;
+        prev = h;
+    }
+    wave_sync();
+    if (IS_DIST) {
+        if (nsyms == 0) {  // src/decompress.rs:588-589 (and src/huffman.rs:41-44)
+            for (int i = lane; i < TSIZE; i += kWave) table[i] = D_INVALID << 4;
+            wave_sync();
+            return BUILD_OK;
+        }
+        if (max_len == 1 && nsyms == 1) {  // src/huffman.rs:45-58: one 1-bit code
+            uint32_t sym = 0;
+            for (int s = lane; s < n; s += kWave) {
+                if (lens[s] == 1) sym = (uint32_t)s;
+            }
+            sym = wave_sum_u32(sym);
+            uint32_t e = Traits::entry(sym, 1);
+            for (int i = lane; i < TSIZE; i += kWave) table[i] = (i & 1) ? (D_INVALID << 4) : e;
+            if (lane == 0) sorted[0] = (uint16_t)sym;
+            wave_sync();
+            return BUILD_OK;
+        }
+    }
+    if (kraft != (1u << 15)) return BUILD_INCOMPLETE;  // src/huffman.rs:72-75
+
+    // Counting sort by (length, symbol) + primary-table fill, one symbol per lane per round.
+    for (int base = 0; base < n; base += kWave) {
+        int s = base + lane;
+        uint32_t l = (s < n) ? lens[s] : 0;
+        uint32_t rank = 0;
+        uint64_t todo = __ballot(l != 0);
+        while (todo) {
+            int leader = __ffsll((unsigned long long)todo) - 1;
+            uint32_t ll = __shfl(l, leader, kWave);
+            uint64_t m = __ballot(l == ll);
+            uint32_t before = uni(cb.run[ll]);
+            if (l == ll) rank = before + __popcll(m & lanemask_lt(lane));
+            wave_sync();
+            if (lane == leader) cb.run[ll] = before + __popcll(m);
+            wave_sync();
+            todo &= ~m;
+        }
+        if (l) {
+            uint32_t cw = cb.first[l] + rank;
+            sorted[cb.offs[l] + rank] = (uint16_t)s;
+            uint32_t rev = __brev(cw) >> (32 - l);
+            if ((int)l <= PB) {
+                uint32_t e = Traits::entry((uint32_t)s, l);
+                for (uint32_t idx = rev; idx < (uint32_t)TSIZE; idx += (1u << l)) table[idx] = e;
+            } else {
+                table[rev & (TSIZE - 1)] = Traits::long_entry();
+            }
+        }
+    }
+    wave_sync();
+    return BUILD_OK;
+}
+
+// Second pass for the litlen table: turn single-literal entries into double-literal entries
+// wherever the next symbol is also a literal and both codes fit in kLitBits bits.
+__device__ inline void add_double_literals(uint32_t* table, int lane) {
+    for (int idx = lane; idx < kLitSize; idx += kWave) {
+        uint32_t e1 = table[idx];
+        uint32_t k1 = (e1 >> 4) & 15;
+        uint32_t n1 = (k1 == K_LIT1) ? (e1 >> 24) : 0;  // [27:24] = bits of the first symbol
+        uint32_t e2 = table[(uint32_t)idx >> n1];
+        uint32_t k2 = (e2 >> 4) & 15;
+        uint32_t n2 = e2 >> 24;
+        wave_sync();  // every lane has read before any lane rewrites an entry
+        if (k1 == K_LIT1 && (k2 == K_LIT1 || k2 == K_LIT2) && n1 + n2 <= (uint32_t)kLitBits) {
+            uint32_t s1 = (e1 >> 8) & 0xFF, s2 = (e2 >> 8) & 0xFF;
+            table[idx] = (n1 + n2) | (K_LIT2 << 4) | (s1 << 8) | (s2 << 16) | (n1 << 24);
+        }
+    }
+    wave_sync();
+}
+
+// Canonical decode of a code longer than the primary index (the reference's secondary
+// tables, src/huffman.rs:138-181).  `bits` holds >= 15 stream bits, LSB first.  Uniform.
+__device__ inline void long_decode(const CodeBook& cb, const uint16_t* sorted, uint64_t bits,
+                                   uint32_t& sym, uint32_t& nbits) {
+    uint32_t code = 0, first = 0, index = 0;
+    sym = 0;
+    nbits = 15;
+    for (int len = 1; len <= 15; len++) {
+        code |= (uint32_t)(bits >> (len - 1)) & 1u;
+        uint32_t count = uni(cb.hist[len]);
+        if (code - first < count) {
+            sym = uni(sorted[index + (code - first)]);
+            nbits = len;
+            return;
+        }
+        index += count;
+        first = (first + count) << 1;
+        code <<= 1;
+    }
+}
+
+}  // namespace fdh

@@ -1,0 +1,135 @@
+/*
+ * fdeflate_hip.h -- C ABI of the MI355X-native batched DEFLATE codec (PNG path).
+ *
+ * Drop-in boundary for image-rs/fdeflate's public API on the PNG hot path
+ * (reference: /root/reference/src/lib.rs:29-36).  The reference has no FFI of its own;
+ * each entry point below names the Rust item it replaces.  A Rust shim crate binds these
+ * with `extern "C"` (see INTEGRATION.md for the exact stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes, no torch / C++ types;
+ *   - `*_batch` entry points take DEVICE pointers (HBM resident) and a hipStream_t passed as
+ *     `void*` (NULL = the null stream); they enqueue work and return without synchronising;
+ *   - function return value = infrastructure status (0 ok, non-zero = HIP / argument failure,
+ *     message via fdh_last_error()); per-stream results are in `status[]`;
+ *   - the library never falls back to a CPU path: without a usable GPU every entry point that
+ *     does work returns FDH_ERR_NO_DEVICE.
+ */
+#ifndef FDEFLATE_HIP_H
+#define FDEFLATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDH_VERSION 0x000100u
+
+/* ---- library-level return codes ---------------------------------------------------- */
+enum {
+    FDH_SUCCESS = 0,
+    FDH_ERR_INVALID_ARGUMENT = 1,
+    FDH_ERR_NO_DEVICE = 2,
+    FDH_ERR_HIP = 3,
+    FDH_ERR_OUT_OF_MEMORY = 4
+};
+
+/* ---- per-stream status --------------------------------------------------------------
+ * 0 = Ok, otherwise 1 + ordinal of `DecompressionError` (src/decompress.rs:14-48), plus one
+ * ABI-only code for `BoundedDecompressionError::OutputTooLarge` (src/decompress.rs:1097-1101). */
+enum {
+    FDH_STREAM_OK = 0,
+    FDH_BAD_ZLIB_HEADER = 1,
+    FDH_INSUFFICIENT_INPUT = 2,
+    FDH_INVALID_BLOCK_TYPE = 3,
+    FDH_INVALID_UNCOMPRESSED_BLOCK_LENGTH = 4,
+    FDH_INVALID_HLIT = 5,
+    FDH_INVALID_HDIST = 6,
+    FDH_INVALID_CODE_LENGTH_REPEAT = 7,
+    FDH_BAD_CODE_LENGTH_HUFFMAN_TREE = 8,
+    FDH_BAD_LITERAL_LENGTH_HUFFMAN_TREE = 9,
+    FDH_BAD_DISTANCE_HUFFMAN_TREE = 10,
+    FDH_INVALID_LITERAL_LENGTH_CODE = 11,
+    FDH_INVALID_DISTANCE_CODE = 12,
+    FDH_INPUT_STARTS_WITH_RUN = 13,
+    FDH_DISTANCE_TOO_FAR_BACK = 14,
+    FDH_WRONG_CHECKSUM = 15,
+    FDH_EXTRA_INPUT = 16,
+    FDH_OUTPUT_TOO_LARGE = 17
+};
+
+/* ---- flags -------------------------------------------------------------------------- */
+#define FDH_FLAG_IGNORE_ADLER32 0x1u /* Decompressor::ignore_adler32, src/decompress.rs:154 */
+#define FDH_FLAG_SERIAL_ONLY    0x2u /* debug/A-B: force the per-symbol wave-serial decoder */
+
+/*
+ * fdh_inflate_batch -- one-shot decode of `n` independent zlib streams, one wavefront each.
+ *
+ * Replaces, per stream i: `decompress_to_vec_bounded(&in[in_off[i]..in_off[i+1]],
+ * out_off[i+1]-out_off[i])` (src/decompress.rs:1111-1144), i.e. a `Decompressor::new()`
+ * (src/decompress.rs:123) driven by `Decompressor::read` (src/decompress.rs:179-337) until
+ * `is_done()` (src/decompress.rs:340), with the slot capacity as `maxlen`.
+ *
+ *   in, in_off[n+1]    packed compressed bytes; stream i = in[in_off[i] .. in_off[i+1])
+ *   out, out_off[n+1]  output slots; capacity of stream i = out_off[i+1] - out_off[i]
+ *                      (< 4 GiB); bytes outside [out_off[i], out_off[i+1]) are never written
+ *   out_len[n]         decoded length (on FDH_OUTPUT_TOO_LARGE: the capacity, slot holds the
+ *                      partial output like `partial_output`); unspecified for other errors
+ *   status[n]          per-stream status (above)
+ *   adler[n]           Adler-32 of the decoded bytes (nullable)
+ *   flags              FDH_FLAG_*
+ * All pointers are device pointers.  Truncated input reports FDH_INSUFFICIENT_INPUT exactly as
+ * the one-shot wrapper does (src/decompress.rs:1135-1136); bytes after the Adler-32 trailer are
+ * ignored (src/decompress.rs:185-187).
+ */
+int fdh_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
+                      const uint64_t *out_off, uint32_t *out_len, uint32_t *status,
+                      uint32_t *adler, uint64_t n, uint32_t flags, void *hip_stream);
+
+/*
+ * fdh_deflate_ultrafast_batch -- `compress_to_vec_ultra_fast` (src/compress/mod.rs:313-317,
+ * UltraFastCompressor src/compress/ultrafast.rs:9-182) of `n` buffers, one wavefront each,
+ * bit-exact with the reference's byte stream.
+ *   in, in_off[n+1]    raw buffers
+ *   out, out_off[n+1]  output slots, capacity >= fdh_ultrafast_bound(len_i) each
+ *   out_len[n]         compressed length; 0xFFFFFFFF if the slot was too small (nothing valid)
+ */
+int fdh_deflate_ultrafast_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
+                                const uint64_t *out_off, uint32_t *out_len, uint64_t n,
+                                void *hip_stream);
+
+/* Worst-case size of an ultra-fast stream: 53 header bytes + ceil((5 + 12*len + 12)/8) + 4. */
+uint64_t fdh_ultrafast_bound(uint64_t len);
+
+/* ---- single-buffer conveniences on HOST memory (names mirror src/lib.rs:29-36) ---------
+ * Each stages through the device (H2D, batch of one, D2H) and synchronises.  Results are
+ * malloc'd; release with fdh_free().  `*stream_status` receives the per-stream status. */
+int fdh_decompress_to_vec(const uint8_t *input, size_t input_len, uint8_t **output,
+                          size_t *output_len, uint32_t *stream_status); /* decompress.rs:1079 */
+int fdh_decompress_to_vec_bounded(const uint8_t *input, size_t input_len, size_t maxlen,
+                                  uint8_t **output, size_t *output_len,
+                                  uint32_t *stream_status); /* decompress.rs:1111 */
+int fdh_compress_to_vec_ultra_fast(const uint8_t *input, size_t input_len, uint8_t **output,
+                                   size_t *output_len); /* compress/mod.rs:313 */
+void fdh_free(void *p);
+
+/* ---- introspection ------------------------------------------------------------------- */
+uint32_t fdh_version(void);
+const char *fdh_status_name(uint32_t stream_status); /* "Ok", "BadZlibHeader", ... */
+const char *fdh_last_error(void);                    /* thread-local message of the last failure */
+int fdh_device_count(void);                          /* usable gfx950 devices, 0 if none */
+
+/* Debug / parity hook: run the device Huffman-table builder (the restatement of
+ * huffman::build_table + CompressedBlock::build_tables, src/huffman.rs:18-184,
+ * src/decompress.rs:561-606) on `code_lengths[320]` and return the decode tables in the
+ * library's device layout (documented in DESIGN.md): litlen[4096], dist[512] u32 entries.
+ * `build_status` = FDH_STREAM_OK or the error build_tables would return.  Device pointers. */
+int fdh_debug_build_tables(const uint8_t *code_lengths320, uint32_t hlit, uint32_t *litlen4096,
+                           uint32_t *dist512, uint32_t *build_status, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,287 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle -- bit-exact."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import streams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def harness():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import gpu_harness
+    return gpu_harness
+
+
+def _norm_gpu_lit(e):
+    nb, kind = e & 15, (e >> 4) & 15
+    if kind == 0:
+        return ("lit1", (e >> 8) & 0xFF, nb)
+    if kind == 1:
+        return ("lit2", (e >> 8) & 0xFF, (e >> 16) & 0xFF, nb)
+    if kind == 2:
+        return ("len", e >> 16, (e >> 8) & 31, nb)
+    if kind == 3:
+        return ("eob", nb)
+    return ("long",)
+
+
+def _norm_ref_lit(e):
+    if e & 0x8000:
+        n = (e >> 8) & 0xF
+        if n == 1:
+            return ("lit1", (e >> 16) & 0xFF, e & 0xFF)
+        return ("lit2", (e >> 16) & 0xFF, (e >> 24) & 0xFF, e & 0xFF)
+    if e & 0x2000:
+        return ("long",)
+    if e & 0x4000:
+        return ("eob", e & 0xFF)
+    return ("len", e >> 16, (e >> 8) & 0xFF, e & 0xFF)
+
+
+def _norm_gpu_dist(e):
+    nb, kind = e & 15, (e >> 4) & 15
+    if kind == 1:
+        return ("dist", e >> 16, (e >> 8) & 15, nb)
+    if kind == 2:
+        return ("long",)
+    return ("invalid",)
+
+
+def _norm_ref_dist(e):
+    if e & 0x8000:
+        return ("dist", e >> 16, (e >> 8) & 0xF, e & 0xFF)
+    if (e >> 8) == 0:
+        return ("invalid",)
+    return ("long",)
+
+
+def _code_length_sets(golden_constants):
+    sets = []
+    sets.append(("fixed", 288, [8] * 144 + [9] * 112 + [7] * 24 + [8] * 8 + [5] * 32))
+    sets.append(("ultrafast", 286, golden_constants["HUFFMAN_LENGTHS"] + [0, 0] + [1] + [0] * 31))
+    sets.append(("long15", 286, streams.long_code_lengths() + [0, 0] + [1, 1] + [0] * 30))
+    sets.append(("mixed_long", 286, streams.mixed_long_lengths() + [0, 0] +
+                 [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 15] + [0] * 16))
+    sets.append(("flat_nodist", 286, streams.flat_lengths() + [0, 0] + [0] * 32))
+    sets.append(("hlit257", 257, [8] * 255 + [9, 9] + [0] * 31 + [5] * 30 + [0, 0]))
+    return sets
+
+
+def test_device_table_builder_matches_reference_tables(harness, golden_constants):
+    import fdeflate_amd as fd
+    for name, hlit, cl in _code_length_sets(golden_constants):
+        assert len(cl) == 320, name
+        rst, rlit, rdist, reof = ob.build_decode_tables(hlit, cl)
+        gst, glit, gdist, geof = fd.debug_build_tables(cl, hlit)
+        assert gst == rst, (name, gst, rst)
+        if rst != 0:
+            continue
+        assert geof == reof, (name, geof, reof)
+        for i in range(4096):
+            assert _norm_gpu_lit(int(glit[i])) == _norm_ref_lit(int(rlit[i])), (name, i)
+        for i in range(512):
+            assert _norm_gpu_dist(int(gdist[i])) == _norm_ref_dist(int(rdist[i])), (name, "dist", i)
+    # golden: the fixed table is the reference constant FIXED_LITLEN_TABLE (tables.rs:142-195)
+    gst, glit, gdist, _ = fd.debug_build_tables([8] * 144 + [9] * 112 + [7] * 24 + [8] * 8 + [5] * 32, 288)
+    for i in range(512):
+        assert _norm_gpu_lit(int(glit[i])) == _norm_ref_lit(golden_constants["FIXED_LITLEN_TABLE"][i])
+    for i in range(32):
+        assert _norm_gpu_dist(int(gdist[i])) == _norm_ref_dist(golden_constants["FIXED_DIST_TABLE"][i])
+
+
+def test_table_builder_error_codes(harness):
+    import fdeflate_amd as fd
+    flat = streams.flat_lengths()
+    cases = {
+        "no_eob": [8] * 256 + [0] * 32 + [1, 1] + [0] * 30,
+        "incomplete": [9] + flat[1:] + [0, 0] + [1, 1] + [0] * 30,
+        "over": flat[:285] + [8] + [0, 0] + [1, 1] + [0] * 30,
+        "dist_incomplete": flat + [0, 0] + [2, 2, 2] + [0] * 29,
+        "dist_lone2": flat + [0, 0] + [2] + [0] * 31,
+        "dist_single_sym5": flat + [0, 0] + [0] * 5 + [1] + [0] * 26,
+    }
+    for name, cl in cases.items():
+        rst = ob.build_decode_tables(286, cl)[0]
+        gst = fd.debug_build_tables(cl, 286)[0]
+        assert gst == rst, (name, gst, rst)
+
+
+def _caps_for(raw_len):
+    return sorted(set([raw_len, raw_len + 1, raw_len + 777, max(raw_len - 1, 0), raw_len // 2, 0]))
+
+
+def test_valid_streams_all_block_types(harness):
+    names, blobs, caps = [], [], []
+    for name, comp, raw in streams.valid_streams():
+        for c in _caps_for(len(raw)):
+            names.append("%s@%d" % (name, c))
+            blobs.append(comp)
+            caps.append(c)
+    harness.assert_inflate_parity(names, blobs, caps)
+
+
+def test_valid_streams_ignore_adler(harness):
+    names, blobs, caps = [], [], []
+    for name, comp, raw in streams.valid_streams():
+        bad = bytearray(comp)
+        bad[-1] ^= 0xFF
+        names.append(name)
+        blobs.append(bytes(bad))
+        caps.append(len(raw) + 3)
+    harness.assert_inflate_parity(names, blobs, caps, flags=1)
+    harness.assert_inflate_parity(names, blobs, caps, flags=0)  # -> WrongChecksum everywhere
+
+
+def test_reference_vectors_corpus_and_zz(harness, golden_manifest):
+    items = streams.corpus_streams()
+    names = [n for n, _ in items]
+    blobs = [b for _, b in items]
+    caps = [1 << 16] * len(items)
+    harness.assert_inflate_parity(names, blobs, caps)
+    harness.assert_inflate_parity(names, blobs, caps, flags=1)
+    # the literal expectations of the reference tests (src/decompress.rs:1344-1384)
+    st, ln, ad, outs, ok = harness.gpu_inflate(blobs, caps, flags=1)
+    by = dict(zip(names, zip(st, ln, ad)))
+    assert tuple(int(x) for x in by["zz_example1"]) == (0, 281, 751299)
+    assert int(by["zz_example2"][0]) == 9 and int(by["zz_example3"][0]) == 9
+    for name, exp in golden_manifest["corpus"].items():
+        s, l, a = by["corpus_" + name[:8]]
+        assert (int(s), int(l), int(a)) == (0, exp["length"], exp["adler32"])
+
+
+def test_error_streams(harness):
+    items = streams.error_streams()
+    names = [n for n, _, _ in items]
+    blobs = [b for _, b, _ in items]
+    for cap in (1 << 16, 4, 0):
+        harness.assert_inflate_parity(names, blobs, [cap] * len(items))
+    st, _, _, _, _ = harness.gpu_inflate(blobs, [1 << 16] * len(items))
+    for (name, _, expect), s in zip(items, st):
+        assert ob.STATUS_NAMES[int(s)] == expect, (name, ob.STATUS_NAMES[int(s)], expect)
+
+
+def test_mutation_fuzz_parity(harness):
+    items = streams.mutation_streams(n_per_seed=60, seeds=(11, 12, 13, 14))
+    names = [n for n, _ in items]
+    blobs = [b for _, b in items]
+    for cap in (1 << 16, 1000):
+        harness.assert_inflate_parity(names, blobs, [cap] * len(items))
+
+
+def test_truncation_sweep(harness):
+    """every prefix of a few streams: InsufficientInput/OutputTooLarge/errors exactly as the
+    reference's one-shot wrapper classifies them"""
+    bases = [zlib.compress(bytes(range(256)) * 3, 6), ob.compress_ultra_fast(b"Hello world! " * 9),
+             ob.compress_stored(b"stored block payload " * 4)]
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    bases.append(c.compress(b"fixed fixed fixed fixed") + c.flush())
+    names, blobs = [], []
+    for bi, base in enumerate(bases):
+        for cut in range(len(base) + 1):
+            names.append("b%d_cut%d" % (bi, cut))
+            blobs.append(base[:cut])
+    for cap in (1 << 12, 100, 24):
+        harness.assert_inflate_parity(names, blobs, [cap] * len(blobs))
+
+
+def test_ultrafast_encode_bit_exact(harness):
+    import fdeflate_amd as fd
+    r = np.random.default_rng(99)
+    raws = [b"", b"Hello world!", bytes(1), bytes(7), bytes(8), bytes(9), bytes(2048), bytes([5]) * 2048,
+            bytes([128]) * 2048, bytes([254]) * 2048, bytes(65536), b"\x01" + bytes(300) + b"\x02",
+            bytes(258 * 3 + 6), bytes(8) + b"\x01" + bytes(7), b"\x00\x00\x05" + bytes(5) + bytes(16) + b"\x09"]
+    for n in (1, 2, 3, 15, 16, 17, 63, 64, 65, 511, 512, 513, 1000, 4096, 65536, 70001):
+        x = r.integers(0, 256, n, dtype=np.uint8)
+        raws.append(x.tobytes())
+        y = x.copy()
+        y[r.random(n) < 0.7] = 0
+        raws.append(y.tobytes())
+        z = x.copy()
+        z[r.random(n) < 0.97] = 0
+        raws.append(z.tobytes())
+    from fdeflate_amd import synth
+    for i in (0, 1, 7, 15, 16, 23):
+        raws.append(synth.gen_stream_np(i, 65536).tobytes())
+    raws.append(bytes(3_000_000) + b"\x07" + bytes(100))  # a run too long for the LDS bit ring
+    res, ok = harness.gpu_deflate(raws)
+    assert ok
+    for i, raw in enumerate(raws):
+        exp = ob.compress_ultra_fast(raw)
+        assert res[i] == exp, (i, len(raw), len(res[i]), len(exp))
+    # single-buffer convenience (host memory) mirrors compress_to_vec_ultra_fast
+    assert fd.compress_to_vec_ultra_fast(b"Hello world!") == ob.compress_ultra_fast(b"Hello world!")
+
+
+def test_host_api_mirror(harness):
+    import fdeflate_amd as fd
+    data = b"Hello world! " * 100
+    assert fd.decompress_to_vec(zlib.compress(data)) == data
+    assert fd.decompress_to_vec(fd.compress_to_vec_ultra_fast(data)) == data
+    assert fd.decompress_to_vec_bounded(zlib.compress(data), len(data)) == data
+    with pytest.raises(fd.OutputTooLarge) as ei:
+        fd.decompress_to_vec_bounded(zlib.compress(data), 10)
+    assert ei.value.partial_output == data[:10]
+    with pytest.raises(fd.DecompressionError) as ei:
+        fd.decompress_to_vec(zlib.compress(data)[:-3])
+    assert ei.value.kind == "InsufficientInput"
+    bad = bytearray(zlib.compress(data))
+    bad[-1] ^= 1
+    with pytest.raises(fd.DecompressionError) as ei:
+        fd.decompress_to_vec(bytes(bad))
+    assert ei.value.kind == "WrongChecksum"
+    big = bytes(1 << 20)  # forces the slot-doubling loop of decompress_to_vec
+    assert fd.decompress_to_vec(zlib.compress(big, 9)) == big
+
+
+def test_c1_single_4k_stream_plumbing(harness):
+    """BASELINE config 1: one 4 KiB stream.  The reference side is the oracle's streaming
+    Decompressor (whole input and byte-at-a-time), the product side the batch-of-one GPU path."""
+    import fdeflate_amd as fd
+    from fdeflate_amd import synth
+    raw = synth.gen_stream_np(3, 4096, png_rows=False).tobytes()
+    comp = ob.compress_ultra_fast(raw)
+    assert ob.decompress_by_chunks(comp, 0) == (0, raw)
+    assert ob.decompress_by_chunks(comp, 1) == (0, raw)
+    assert fd.compress_to_vec_ultra_fast(raw) == comp
+    assert fd.decompress_to_vec(comp) == raw
+
+
+def test_batch_roundtrip_at_scale(harness):
+    """4096 x 64 KiB: encode on the GPU, decode on the GPU; every stream Ok, lengths exact,
+    decoded == raw, and the Adler-32 the decoder reports equals the trailer the encoder wrote
+    (a checksum of checksums; the oracle spot-checks a sample bit-exactly)."""
+    import torch
+    import fdeflate_amd as fd
+    from fdeflate_amd import synth
+    n, L = 4096, 65536
+    raw = synth.gen_batch_torch(0, n, L)
+    assert np.array_equal(raw[5].cpu().numpy(), synth.gen_stream_np(5, L))
+    bound = (fd.ultrafast_bound(L) + 15) & ~15
+    in_off = torch.arange(n + 1, dtype=torch.int64, device="cuda") * L
+    c_off = torch.arange(n + 1, dtype=torch.int64, device="cuda") * bound
+    comp = torch.zeros(n * bound, dtype=torch.uint8, device="cuda")
+    clen = fd.deflate_ultrafast_batch(raw.view(-1), in_off, comp, c_off)
+    torch.cuda.synchronize()
+    clen_h = clen.cpu().numpy()
+    for i in (0, 7, 15, 100, 4095):
+        exp = ob.compress_ultra_fast(raw[i].cpu().numpy().tobytes())
+        got = comp[i * bound:i * bound + int(clen_h[i])].cpu().numpy().tobytes()
+        assert got == exp, i
+    # decode from the padded slots (trailing bytes after the trailer are ignored by the format)
+    out = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    out_len, status, adler = fd.inflate_batch(comp, c_off, out, in_off)
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0
+    assert bool((out_len == L).all())
+    assert torch.equal(out, raw.view(-1))
+    # trailer = last 4 bytes of each stream, big-endian
+    idx = (c_off[:-1] + clen.to(torch.int64))[:, None] + torch.arange(-4, 0, device="cuda")[None, :]
+    tr = comp[idx].to(torch.int64)
+    trailer = (tr[:, 0] << 24) | (tr[:, 1] << 16) | (tr[:, 2] << 8) | tr[:, 3]
+    assert torch.equal(trailer, adler.to(torch.int64) & 0xFFFFFFFF)
