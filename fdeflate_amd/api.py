@@ -26,6 +26,8 @@ STATUS_NAMES = [
 OUTPUT_TOO_LARGE = 17
 FLAG_IGNORE_ADLER32 = 1
 FLAG_SERIAL_ONLY = 2
+FLAG_GENERAL_ONLY = 4
+FLAG_NO_RECHECK = 8
 
 
 class DecompressionError(Exception):

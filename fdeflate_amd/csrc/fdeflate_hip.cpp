@@ -8,12 +8,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 extern "C" {
-int fdh_launch_inflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
-                               uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
-                               hipStream_t stream);
+int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                       uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
+                       hipStream_t stream);
+int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status);
 int fdh_launch_build_tables_debug(const uint8_t* code_lengths, uint32_t hlit, uint32_t* litlen, uint32_t* dist,
                                   uint32_t* build_status, hipStream_t stream);
 int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
@@ -44,6 +46,24 @@ bool have_device() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return false;
     return n > 0;
+}
+
+// The shared decode tables of the ultra-fast prefix are built on the device once per device.
+std::mutex g_canon_mutex;
+bool g_canon_ready[64] = {};
+
+int ensure_canon_tables(hipStream_t stream) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FDH_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_canon_mutex);
+    if (g_canon_ready[dev]) return FDH_SUCCESS;
+    uint32_t st = 0xFFFFFFFFu;
+    int rc = fdh_launch_canon_build(stream, &st);
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "canonical table build");
+    if (st != 0) return fail(FDH_ERR_HIP, "canonical table build returned status " + std::to_string(st));
+    g_canon_ready[dev] = true;
+    return FDH_SUCCESS;
 }
 
 const char* kStatusNames[] = {
@@ -88,8 +108,10 @@ int fdh_inflate_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* out, c
     if (!in_off || !out_off || !out_len || !status) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
     if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many streams in one call (max 2^31-1)");
     if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
-    int rc = fdh_launch_inflate_general(in, in_off, out, out_off, out_len, status, adler, n, flags,
-                                        static_cast<hipStream_t>(hip_stream));
+    int rc = ensure_canon_tables(static_cast<hipStream_t>(hip_stream));
+    if (rc != FDH_SUCCESS) return rc;
+    rc = fdh_launch_inflate(in, in_off, out, out_off, out_len, status, adler, n, flags,
+                            static_cast<hipStream_t>(hip_stream));
     if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "inflate kernel launch");
     return FDH_SUCCESS;
 }

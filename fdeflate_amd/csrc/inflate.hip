@@ -1,7 +1,54 @@
 // inflate.hip -- batched zlib decode kernels (gfx950).  One independent stream per wavefront.
+//
+// Two kernels share the per-stream decoder of inflate_stream.h:
+//
+//   inflate_canon_kernel    8 wavefronts (= 8 streams) per workgroup.  Streams that start with
+//                           the ultra-fast encoder's fixed 53-byte + 5-bit prefix (reference
+//                           src/compress/ultrafast.rs:82-88: zlib header + one final dynamic
+//                           block header) all use the same Huffman tables, so the workgroup
+//                           stages ONE copy of them in LDS (built once per device from those
+//                           header bytes by canon_build_kernel) and each wavefront only needs
+//                           its 7 KiB of input/output staging: 16 wavefronts per CU.
+//                           Every other stream is marked PENDING.
+//   inflate_general_kernel  1 wavefront per workgroup with private tables in LDS: any zlib
+//                           stream (stored / fixed / dynamic blocks, multi-block).  Runs over
+//                           the PENDING streams only when it follows the canon kernel.
+//
+// Exactness guard: results other than Ok that depend on how literals were paired by the
+// double-literal table at the very end of a truncated input, and all hard errors, are re-derived
+// by the symbol-serial decoder, whose pairing is the reference's (DESIGN.md "error parity").
 #include "inflate_stream.h"
 
 namespace fdh {
+
+#include "uf_table_data.inc"
+
+constexpr uint32_t kPending = 0xFFFFFFFFu;         // not decoded yet, tiles allowed
+constexpr uint32_t kPendingSerial = 0xFFFFFFFEu;   // not decoded yet, serial decoder only
+constexpr uint32_t kCanonBits = 53 * 8 + 5;        // ultrafast.rs:87-88
+constexpr int kCanonWaves = 8;
+
+struct CanonTables {
+    uint32_t lit[kLitSize];
+    uint32_t dist[kDistSize];
+    uint32_t eof[4];
+    uint32_t hdr[16];  // the prefix as little-endian dwords (14 used)
+    uint32_t status;   // build status (ST_OK expected)
+};
+__device__ CanonTables g_canon;
+
+__device__ const uint8_t g_canon_header[64] = {
+    kUfHeaderData[0],  kUfHeaderData[1],  kUfHeaderData[2],  kUfHeaderData[3],  kUfHeaderData[4],
+    kUfHeaderData[5],  kUfHeaderData[6],  kUfHeaderData[7],  kUfHeaderData[8],  kUfHeaderData[9],
+    kUfHeaderData[10], kUfHeaderData[11], kUfHeaderData[12], kUfHeaderData[13], kUfHeaderData[14],
+    kUfHeaderData[15], kUfHeaderData[16], kUfHeaderData[17], kUfHeaderData[18], kUfHeaderData[19],
+    kUfHeaderData[20], kUfHeaderData[21], kUfHeaderData[22], kUfHeaderData[23], kUfHeaderData[24],
+    kUfHeaderData[25], kUfHeaderData[26], kUfHeaderData[27], kUfHeaderData[28], kUfHeaderData[29],
+    kUfHeaderData[30], kUfHeaderData[31], kUfHeaderData[32], kUfHeaderData[33], kUfHeaderData[34],
+    kUfHeaderData[35], kUfHeaderData[36], kUfHeaderData[37], kUfHeaderData[38], kUfHeaderData[39],
+    kUfHeaderData[40], kUfHeaderData[41], kUfHeaderData[42], kUfHeaderData[43], kUfHeaderData[44],
+    kUfHeaderData[45], kUfHeaderData[46], kUfHeaderData[47], kUfHeaderData[48], kUfHeaderData[49],
+    kUfHeaderData[50], kUfHeaderData[51], kUfHeaderData[52], kUfHeaderData[53]};
 
 struct InflateBatchArgs {
     const uint8_t* in;
@@ -13,14 +60,10 @@ struct InflateBatchArgs {
     uint32_t* adler;
     uint64_t n;
     uint32_t flags;
+    uint32_t only_pending;
 };
 
-// General kernel: workgroup = one wavefront = one stream, private decode tables in LDS.
-__global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs a) {
-    __shared__ WaveLds lds;
-    const int lane = threadIdx.x;
-    const uint64_t sid = blockIdx.x;
-    if (sid >= a.n) return;
+__device__ __forceinline__ StreamArgs stream_args(const InflateBatchArgs& a, uint64_t sid) {
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
     const uint64_t o0 = a.out_off[sid], o1 = a.out_off[sid + 1];
     StreamArgs s;
@@ -32,8 +75,48 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
     s.buf_lo = a.in;
     s.buf_hi = a.in + a.in_off[a.n];
     s.flags = a.flags;
-    Inflater inf(lds, lane);
-    StreamResult r = inf.run(s);
+    return s;
+}
+
+// A result the tile decoder may have classified differently from the reference: anything but Ok
+// and a "robust" OutputTooLarge / InsufficientInput far away from the end of the input.
+__device__ __forceinline__ bool needs_serial_recheck(const StreamResult& r, uint32_t flags) {
+    if (flags & 8u) return false;  // FDH_FLAG_NO_RECHECK (tests: the tile decoder on its own)
+    if (r.status == ST_OK) return false;
+    if (r.status == ST_OUTPUT_TOO_LARGE || r.status == ST_INSUFFICIENT_INPUT) return r.ambiguous;
+    return true;
+}
+
+struct GeneralLds {
+    TableSet tables;
+    WaveIo io;
+    HeaderScratch hs;
+};
+
+// General kernel: workgroup = one wavefront = one stream, private decode tables in LDS.
+__global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs a) {
+    __shared__ GeneralLds lds;
+    const int lane = threadIdx.x;
+    const uint64_t sid = blockIdx.x;
+    if (sid >= a.n) return;
+    bool tiles = !(a.flags & 2u);
+    if (a.only_pending) {
+        uint32_t st = a.status[sid];
+        if (st != kPending && st != kPendingSerial) return;
+        if (st == kPendingSerial) tiles = false;
+    }
+    const StreamArgs s = stream_args(a, sid);
+    Inflater inf(lds.tables, lds.io, &lds.hs, lane);
+    StreamResult r;
+    if (tiles) {
+        inf.init(s);
+        r = inf.run<true, false>();
+        if (needs_serial_recheck(r, a.flags)) tiles = false;
+    }
+    if (!tiles) {
+        inf.init(s);
+        r = inf.run<false, false>();
+    }
     if (lane == 0) {
         a.status[sid] = r.status;
         a.out_len[sid] = r.out_len;
@@ -41,21 +124,119 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
     }
 }
 
+struct CanonLds {
+    TableSet tables;
+    WaveIo io[kCanonWaves];
+};
+
+__global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(InflateBatchArgs a) {
+    __shared__ CanonLds lds;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x / kWave;
+    // stage the shared tables: 16 B per lane, coalesced, served from L2 after the first workgroups
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(g_canon.lit);
+        uint4* dst = reinterpret_cast<uint4*>(lds.tables.lit);
+        for (int i = threadIdx.x; i < kLitSize / 4; i += kCanonWaves * kWave) dst[i] = src[i];
+        const uint4* srcd = reinterpret_cast<const uint4*>(g_canon.dist);
+        uint4* dstd = reinterpret_cast<uint4*>(lds.tables.dist);
+        for (int i = threadIdx.x; i < kDistSize / 4; i += kCanonWaves * kWave) dstd[i] = srcd[i];
+        if (threadIdx.x < 4) lds.tables.eof[threadIdx.x] = g_canon.eof[threadIdx.x];
+    }
+    __syncthreads();
+    const uint64_t sid = (uint64_t)blockIdx.x * kCanonWaves + wid;
+    if (sid >= a.n) return;
+    const StreamArgs s = stream_args(a, sid);
+    Inflater inf(lds.tables, lds.io[wid], nullptr, lane);
+    inf.init(s);
+    // does the stream start with the canonical prefix?  lane k compares stream dword k
+    bool mismatch = false;
+    if (lane < 14) {
+        uint32_t wbit = inf.mis * 8 + 32 * lane;
+        uint32_t d = wbit >> 5, sh = wbit & 31;
+        uint32_t lo = lds.io[wid].in_ring[d & (kInRingDw - 1)];
+        uint32_t hi = lds.io[wid].in_ring[(d + 1) & (kInRingDw - 1)];
+        uint32_t v = __builtin_amdgcn_alignbit(hi, lo, sh);
+        uint32_t ref = g_canon.hdr[lane];
+        if (lane == 13) {
+            v &= (1u << (kCanonBits - 13 * 32)) - 1;
+        }
+        mismatch = v != ref;
+    }
+    const bool canonical = !__any(mismatch) && s.in_len * 8 >= kCanonBits;
+    if (!canonical) {
+        if (lane == 0) a.status[sid] = kPending;
+        return;
+    }
+    inf.left -= kCanonBits;
+    inf.seek(kCanonBits);
+    inf.last_block = true;  // BFINAL = 1 is part of the prefix
+    inf.eof_code = lds.tables.eof[0];
+    inf.eof_mask = lds.tables.eof[1];
+    inf.eof_bits = lds.tables.eof[2];
+    StreamResult r = inf.run<true, true>();
+    if (lane == 0) {
+        if (needs_serial_recheck(r, a.flags)) {
+            a.status[sid] = kPendingSerial;
+        } else {
+            a.status[sid] = r.status;
+            a.out_len[sid] = r.out_len;
+            if (a.adler) a.adler[sid] = r.adler;
+        }
+    }
+}
+
+// Parses the canonical prefix once per device and keeps the resulting tables in g_canon.
+__global__ __launch_bounds__(kWave) void canon_build_kernel() {
+    __shared__ GeneralLds lds;
+    const int lane = threadIdx.x;
+    StreamArgs s;
+    s.in = g_canon_header;
+    s.in_len = 54;
+    s.out = nullptr;
+    s.cap = 0;
+    s.buf_lo = g_canon_header;
+    s.buf_hi = g_canon_header + 64;
+    s.flags = 0;
+    Inflater inf(lds.tables, lds.io, &lds.hs, lane);
+    inf.init(s);
+    uint32_t rc = inf.parse_zlib_header();
+    if (rc == RC_OK) rc = inf.parse_block_header();
+    wave_sync();
+    for (int i = lane; i < kLitSize; i += kWave) g_canon.lit[i] = lds.tables.lit[i];
+    for (int i = lane; i < kDistSize; i += kWave) g_canon.dist[i] = lds.tables.dist[i];
+    if (lane < 14) {
+        uint32_t w = (uint32_t)g_canon_header[4 * lane] | ((uint32_t)g_canon_header[4 * lane + 1] << 8) |
+                     ((uint32_t)g_canon_header[4 * lane + 2] << 16) | ((uint32_t)g_canon_header[4 * lane + 3] << 24);
+        if (lane == 13) w &= (1u << (kCanonBits - 13 * 32)) - 1;
+        g_canon.hdr[lane] = w;
+    }
+    if (lane == 0) {
+        g_canon.eof[0] = inf.eof_code;
+        g_canon.eof[1] = inf.eof_mask;
+        g_canon.eof[2] = inf.eof_bits;
+        g_canon.eof[3] = 0;
+        bool ok = rc == RC_OK && inf.last_block && inf.consumed_bits() == kCanonBits;
+        g_canon.status = ok ? (uint32_t)ST_OK : (rc == RC_OK ? 0xBADu : rc);
+    }
+}
+
 // Debug / parity hook behind fdh_debug_build_tables.
 __global__ __launch_bounds__(kWave) void build_tables_debug_kernel(const uint8_t* code_lengths, uint32_t hlit,
                                                                    uint32_t* litlen, uint32_t* dist,
                                                                    uint32_t* build_status) {
-    __shared__ WaveLds lds;
+    __shared__ GeneralLds lds;
     const int lane = threadIdx.x;
-    for (int i = lane; i < 320; i += kWave) lds.lens[i] = code_lengths[i];
-    for (int i = lane; i < kLitSize; i += kWave) lds.lit[i] = 0xFFFFFFFFu;
-    for (int i = lane; i < kDistSize; i += kWave) lds.dist[i] = 0xFFFFFFFFu;
+    for (int i = lane; i < 320; i += kWave) lds.hs.lens[i] = code_lengths[i];
+    for (int i = lane; i < kLitSize; i += kWave) lds.tables.lit[i] = 0xFFFFFFFFu;
+    for (int i = lane; i < kDistSize; i += kWave) lds.tables.dist[i] = 0xFFFFFFFFu;
     wave_sync();
-    Inflater inf(lds, lane);
+    Inflater inf(lds.tables, lds.io, &lds.hs, lane);
+    inf.eof_code = inf.eof_mask = inf.eof_bits = 0;
     uint32_t st = inf.build_block_tables(hlit);
     wave_sync();
-    for (int i = lane; i < kLitSize; i += kWave) litlen[i] = lds.lit[i];
-    for (int i = lane; i < kDistSize; i += kWave) dist[i] = lds.dist[i];
+    for (int i = lane; i < kLitSize; i += kWave) litlen[i] = lds.tables.lit[i];
+    for (int i = lane; i < kDistSize; i += kWave) dist[i] = lds.tables.dist[i];
     if (lane == 0) {
         build_status[0] = st;
         build_status[1] = inf.eof_code;
@@ -66,11 +247,43 @@ __global__ __launch_bounds__(kWave) void build_tables_debug_kernel(const uint8_t
 
 }  // namespace fdh
 
-extern "C" int fdh_launch_inflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
-                                          const uint64_t* out_off, uint32_t* out_len, uint32_t* status,
-                                          uint32_t* adler, uint64_t n, uint32_t flags, hipStream_t stream) {
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags};
+#ifdef FDH_DEBUG_TILES
+extern "C" int fdh_debug_read(uint32_t* host, uint32_t nwords, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host + 8, HIP_SYMBOL(fdh::g_dbg), (nwords - 8) * 4, 32);
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_dbg_n), 4);
+    if (reset) { uint32_t z = 0; hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_dbg_n), &z, 4); }
+    return 0;
+}
+#endif
+
+extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status) {
+    hipLaunchKernelGGL(fdh::canon_build_kernel, dim3(1), dim3(fdh::kWave), 0, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return (int)e;
+    fdh::CanonTables* dev = nullptr;
+    e = hipGetSymbolAddress(reinterpret_cast<void**>(&dev), HIP_SYMBOL(fdh::g_canon));
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(host_status, &dev->status, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    return (int)e;
+}
+
+extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                                  uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
+                                  hipStream_t stream) {
     if (n == 0) return 0;
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0};
+    if (flags & 6u) {  // FDH_FLAG_SERIAL_ONLY (2) / debug: general kernel only, tiles allowed (4)
+        hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
+        return (int)hipGetLastError();
+    }
+    unsigned blocks = (unsigned)((n + fdh::kCanonWaves - 1) / fdh::kCanonWaves);
+    hipLaunchKernelGGL(fdh::inflate_canon_kernel, dim3(blocks), dim3(fdh::kCanonWaves * fdh::kWave), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    a.only_pending = 1;
     hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
     return (int)hipGetLastError();
 }

@@ -1,6 +1,16 @@
-// inflate_stream.h -- one zlib stream per wavefront: bit reader over an LDS-staged input
-// window, LDS output ring with coalesced 16-B flushes + fused Adler-32, and the zlib/deflate
-// state machine with the reference's one-shot semantics.
+// inflate_stream.h -- one zlib stream per wavefront.
+//
+//   * bit reader over an LDS-staged input window (coalesced 16 B/lane loads of the packed batch)
+//   * LDS output ring with coalesced 16-B line flushes and a fused Adler-32
+//   * the zlib/deflate state machine with the reference's one-shot semantics
+//   * two decoders for compressed-block data:
+//       serial_token()  one symbol at a time, all lanes uniform: the exact restatement of the
+//                       reference's careful loop (every error / truncation rule)
+//       tile_step()     64 lanes x 64 bits speculative parallel decode: every lane decodes the
+//                       code chain of its own 8-byte chunk from a guessed start, chains are
+//                       re-synchronised lane to lane (Huffman codes self-synchronise), output
+//                       offsets come from a wave prefix sum, literals are scattered into the
+//                       output ring in parallel and matches are replayed in order.
 //
 // Restates (behaviour, not code) Decompressor::read and its helpers:
 //   reference src/decompress.rs:179-337 (state machine), :344-438 (block header),
@@ -11,7 +21,7 @@
 // buffer; it returns and the wrapper classifies (src/decompress.rs:1126-1139): done -> Ok,
 // output full -> OutputTooLarge, otherwise InsufficientInput.  Every place the reference
 // "waits for more bits" (`nbits < X`, all X <= 48 < 56 so `nbits` there equals the number of
-// unread stream bits) is a `stuck()` here with the same threshold on `left`.
+// unread stream bits) is RC_STUCK here with the same threshold on `left`.
 #pragma once
 #include "inflate_tables.h"
 
@@ -22,18 +32,31 @@ constexpr int kInRingDw = 2 * kInChunk / 4; // two chunks
 constexpr int kOutRing = 4096;              // bytes, power of two
 constexpr int kOutMask = kOutRing - 1;
 constexpr int kFlushSlack = 64;
+constexpr int kMaxMatches = 128;            // match tokens replayed per tile
+constexpr int kTileBits = 64;               // stream bits owned by one lane of a tile
 
-struct __attribute__((aligned(16))) WaveLds {
+// Decode tables of the current block.
+struct __attribute__((aligned(16))) TableSet {
     uint32_t lit[kLitSize];
     uint32_t dist[kDistSize];
-    uint32_t in_ring[kInRingDw];
-    uint8_t out_ring[kOutRing];
-    uint32_t cl[kClSize];
     CodeBook lit_cb;
     CodeBook dist_cb;
-    CodeBook cl_cb;
     uint16_t lit_sorted[288];
     uint16_t dist_sorted[32];
+    uint32_t eof[4];  // code, mask, bits of the end-of-block symbol (reference eof_code/mask/bits)
+};
+
+// Per-wavefront staging.
+struct __attribute__((aligned(16))) WaveIo {
+    uint32_t in_ring[kInRingDw];
+    uint8_t out_ring[kOutRing];
+    uint32_t mlist[2 * kMaxMatches];
+};
+
+// Scratch for dynamic block headers.
+struct __attribute__((aligned(16))) HeaderScratch {
+    uint32_t cl[kClSize];
+    CodeBook cl_cb;
     uint16_t cl_sorted[32];
     uint8_t lens[320 + 16];
 };
@@ -45,18 +68,82 @@ struct StreamArgs {
     uint32_t cap;             // slot capacity
     const uint8_t* buf_lo;    // readable range of the whole packed input buffer
     const uint8_t* buf_hi;
-    uint32_t flags;
+    uint32_t flags;           // FDH_FLAG_*
 };
 
 struct StreamResult {
     uint32_t status, out_len, adler;
+    bool ambiguous;  // ended "stuck" close to the end of the input (see inflate.hip)
 };
+
+enum : uint32_t { RC_OK = 0, RC_EOB = 0x100, RC_STUCK = 0x101 };  // anything else: a StreamStatus
+
+#ifdef FDH_DEBUG_TILES
+__device__ uint32_t g_dbg[1 << 16];
+__device__ uint32_t g_dbg_n;
+#endif
+
+// Stores output [flushed, target) to global memory and folds it into the Adler-32.  target is
+// opos rounded down to a 16-B line unless `final`.  Ring index of output position p is
+// (p + gmis) & kOutMask, so 16-B lines of the global slot are 16-B lines of the ring.
+struct FlushState {
+    uint32_t flushed, adler_a, adler_b;
+};
+__device__ __attribute__((noinline)) FlushState flush_ring(WaveIo* iop, uint8_t* out_al, uint32_t gmis,
+                                                           uint32_t opos, uint32_t flushed, uint32_t adler_a,
+                                                           uint32_t adler_b, bool final, int lane) {
+    WaveIo& io = *iop;
+    wave_sync();
+    uint32_t q_lo = flushed + gmis;
+    uint32_t q_hi = opos + gmis;
+    if (!final) q_hi &= ~15u;
+    if (q_hi <= q_lo) return FlushState{flushed, adler_a, adler_b};
+    for (uint32_t it = q_lo & ~15u; it < q_hi; it += kWave * 16) {
+        uint32_t lq = it + lane * 16;  // this lane's line, q-space
+        uint32_t blk_hi = min(q_hi, it + kWave * 16);
+        uint32_t blk_lo = max(q_lo, it);
+        uint32_t s = 0, t = 0;
+        if (lq < blk_hi && lq + 16 > blk_lo) {
+            uint32_t lo = (blk_lo > lq) ? blk_lo - lq : 0;
+            uint32_t hi = (blk_hi < lq + 16) ? blk_hi - lq : 16;
+            uint32_t W = blk_hi - lq;  // weight of byte j is W - j
+            if (lo == 0 && hi == 16) {
+                uint4 v = *reinterpret_cast<const uint4*>(&io.out_ring[lq & kOutMask]);
+                *reinterpret_cast<uint4*>(out_al + lq) = v;
+                s = bytesum4(v.x) + bytesum4(v.y) + bytesum4(v.z) + bytesum4(v.w);
+                uint32_t u = bytedot4(v.x, 0x03020100u, 0);
+                u = bytedot4(v.y, 0x07060504u, u);
+                u = bytedot4(v.z, 0x0b0a0908u, u);
+                u = bytedot4(v.w, 0x0f0e0d0cu, u);
+                t = W * s - u;
+            } else {
+                for (uint32_t j = lo; j < hi; j++) {
+                    uint32_t b = io.out_ring[(lq + j) & kOutMask];
+                    out_al[lq + j] = (uint8_t)b;
+                    s += b;
+                    t += (W - j) * b;
+                }
+            }
+        }
+        uint32_t S = wave_sum_u32(s);
+        uint32_t Tt = wave_sum_u32(t);
+        uint32_t Lb = blk_hi - blk_lo;
+        adler_b = (uint32_t)(((uint64_t)adler_b + (uint64_t)Lb * adler_a + Tt) % kAdlerMod);
+        adler_a = (adler_a + S) % kAdlerMod;
+    }
+    flushed = q_hi - gmis;
+    wave_sync();
+    return FlushState{flushed, adler_a, adler_b};
+}
 
 // ---------------------------------------------------------------------------------------
 struct Inflater {
-    WaveLds& L;
+    TableSet& T;
+    WaveIo& io;
+    HeaderScratch* hs;
     const int lane;
     // ---- input window / bit reader (all uniform) ----
+    const uint8_t* in;
     const uint8_t* base16;  // 16-B aligned address at or below the first stream byte
     uint32_t mis;           // first stream byte = base16 + mis
     uint64_t win_bytes;     // mis + in_len
@@ -72,15 +159,18 @@ struct Inflater {
     uint32_t gmis;          // out & 15
     uint32_t cap, opos, flushed;
     uint32_t adler_a, adler_b;
-    bool want_adler;
     // ---- block state ----
     uint32_t eof_code, eof_mask, eof_bits;
     bool fixed_built;
+    bool last_block;
+    uint32_t flags;
+    uint32_t serial_credit;  // tokens to decode serially before the next tile attempt
 
-    __device__ Inflater(WaveLds& l, int ln) : L(l), lane(ln) {}
+    __device__ __forceinline__ Inflater(TableSet& t, WaveIo& w, HeaderScratch* h, int ln)
+        : T(t), io(w), hs(h), lane(ln) {}
 
     // ------------------------------------------------------------------ input window
-    __device__ void load_chunk(uint32_t c) {
+    __device__ __forceinline__ void load_chunk(uint32_t c) {
         uint64_t w0 = (uint64_t)c * kInChunk + (uint64_t)lane * 16;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (w0 < win_bytes) {
@@ -88,34 +178,34 @@ struct Inflater {
             if (p >= buf_lo && p + 16 <= buf_hi) {
                 v = *reinterpret_cast<const uint4*>(p);
             } else {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (int j = 0; j < 16; j++) {
-                    if (p + j >= buf_lo && p + j < buf_hi) w[j >> 2] |= (uint32_t)p[j] << ((j & 3) * 8);
+                uint64_t lo = 0, hi = 0;
+                for (int j = 0; j < 8; j++) {
+                    if (p + j >= buf_lo && p + j < buf_hi) lo |= (uint64_t)p[j] << (j * 8);
+                    if (p + 8 + j >= buf_lo && p + 8 + j < buf_hi) hi |= (uint64_t)p[8 + j] << (j * 8);
                 }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
             }
             uint64_t rem = win_bytes - w0;  // bytes of this stream in the lane's 16
             if (rem < 16) {                 // zero what lies past the end of the stream
                 uint32_t r = (uint32_t)rem;
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t lo = k * 4;
-                    if (r <= lo) w[k] = 0;
-                    else if (r < lo + 4) w[k] &= (1u << ((r - lo) * 8)) - 1;
-                }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                v.x = r >= 4 ? v.x : (r == 0 ? 0 : v.x & ((1u << (r * 8)) - 1));
+                v.y = r >= 8 ? v.y : (r <= 4 ? 0 : v.y & ((1u << ((r - 4) * 8)) - 1));
+                v.z = r >= 12 ? v.z : (r <= 8 ? 0 : v.z & ((1u << ((r - 8) * 8)) - 1));
+                v.w = r <= 12 ? 0 : v.w & ((1u << ((r - 12) * 8)) - 1);
             }
         }
-        *reinterpret_cast<uint4*>(&L.in_ring[(c & 1) * (kInChunk / 4) + lane * 4]) = v;
+        *reinterpret_cast<uint4*>(&io.in_ring[(c & 1) * (kInChunk / 4) + lane * 4]) = v;
     }
 
-    __device__ void ensure_dw(uint32_t dw) {
+    // Makes the chunk holding window dword `dw` resident.  Loading chunk c evicts chunk c-2; the
+    // reader never looks back more than the 64 bits held in `bb`, and a tile names both ends of
+    // its window, so nothing that is still needed is ever evicted.
+    __device__ __forceinline__ void ensure_dw(uint32_t dw) {
         uint32_t c = dw / (kInChunk / 4);
-        if (c + 1 >= loaded) {
+        if (c >= loaded) {
             wave_sync();
-            while (loaded <= c + 1) {
-                if (loaded + 2 <= c) loaded = c;  // after a seek: skip chunks nobody will read
+            while (loaded <= c) {
+                if (loaded + 1 < c) loaded = c - 1;  // after a seek: skip chunks nobody will read
                 load_chunk(loaded);
                 loaded++;
             }
@@ -123,130 +213,87 @@ struct Inflater {
         }
     }
 
-    __device__ void seek(uint64_t bitpos) {  // bitpos relative to the first stream byte
+    __device__ __forceinline__ void seek(uint64_t bitpos) {  // bitpos relative to the first stream byte
         uint64_t wbit = bitpos + (uint64_t)mis * 8;
         next_dw = (uint32_t)(wbit >> 5);
         uint32_t c = next_dw / (kInChunk / 4);
         if (!(c + 2 == loaded || c + 1 == loaded)) loaded = c;  // ring content unusable
         ensure_dw(next_dw);
         uint32_t sh = (uint32_t)wbit & 31;
-        bb = (uint64_t)(uni(L.in_ring[next_dw & (kInRingDw - 1)]) >> sh);
+        bb = (uint64_t)(uni(io.in_ring[next_dw & (kInRingDw - 1)]) >> sh);
         bbn = 32 - sh;
         next_dw++;
     }
 
-    __device__ void refill() {  // afterwards bbn >= 33
+    __device__ __forceinline__ void refill() {  // afterwards bbn >= 33
         if (bbn <= 32) {
             ensure_dw(next_dw);
-            uint32_t w = uni(L.in_ring[next_dw & (kInRingDw - 1)]);
+            uint32_t w = uni(io.in_ring[next_dw & (kInRingDw - 1)]);
             bb |= (uint64_t)w << bbn;
             bbn += 32;
             next_dw++;
         }
     }
-    __device__ void consume(uint32_t n) {
+    __device__ __forceinline__ void consume(uint32_t n) {
         bb >>= n;
         bbn -= n;
         left -= n;
     }
-    __device__ uint64_t consumed_bits() const { return (win_bytes - mis) * 8 - left; }
+    __device__ __forceinline__ uint64_t consumed_bits() const { return (win_bytes - mis) * 8 - left; }
 
     // ------------------------------------------------------------------ output ring
-    // Ring index of output position p is (p + gmis) & kOutMask, so 16-B lines of the global
-    // slot are 16-B lines of the ring.
-    __device__ void put_byte(uint32_t b) {
-        if (lane == 0) L.out_ring[(opos + gmis) & kOutMask] = (uint8_t)b;
+    __device__ __forceinline__ void put_byte(uint32_t b) {
+        if (lane == 0) io.out_ring[(opos + gmis) & kOutMask] = (uint8_t)b;
         opos++;
     }
-
-    // Stores output [flushed, target) to global memory and folds it into the Adler-32.
-    // target is opos rounded down to a line unless `final`.
-    __device__ void flush(bool final) {
-        wave_sync();
-        uint32_t q_lo = flushed + gmis;
-        uint32_t q_hi = opos + gmis;
-        if (!final) q_hi &= ~15u;
-        if (q_hi <= q_lo) return;
-        for (uint32_t it = q_lo & ~15u; it < q_hi; it += kWave * 16) {
-            uint32_t lq = it + lane * 16;       // this lane's line, q-space
-            uint32_t blk_hi = min(q_hi, it + kWave * 16);
-            uint32_t blk_lo = max(q_lo, it);
-            uint32_t s = 0, t = 0;
-            if (lq < blk_hi && lq + 16 > blk_lo) {
-                uint32_t lo = (blk_lo > lq) ? blk_lo - lq : 0;
-                uint32_t hi = (blk_hi < lq + 16) ? blk_hi - lq : 16;
-                uint32_t W = blk_hi - lq;  // weight of byte j is W - j
-                if (lo == 0 && hi == 16) {
-                    uint4 v = *reinterpret_cast<const uint4*>(&L.out_ring[lq & kOutMask]);
-                    *reinterpret_cast<uint4*>(out_al + lq) = v;
-                    if (want_adler) {
-                        s = bytesum4(v.x) + bytesum4(v.y) + bytesum4(v.z) + bytesum4(v.w);
-                        uint32_t u = bytedot4(v.x, 0x03020100u, 0);
-                        u = bytedot4(v.y, 0x07060504u, u);
-                        u = bytedot4(v.z, 0x0b0a0908u, u);
-                        u = bytedot4(v.w, 0x0f0e0d0cu, u);
-                        t = W * s - u;
-                    }
-                } else {
-                    for (uint32_t j = lo; j < hi; j++) {
-                        uint32_t b = L.out_ring[(lq + j) & kOutMask];
-                        out_al[lq + j] = (uint8_t)b;
-                        s += b;
-                        t += (W - j) * b;
-                    }
-                }
-            }
-            if (want_adler) {
-                uint32_t S = wave_sum_u32(s);
-                uint32_t T = wave_sum_u32(t);
-                uint32_t Lb = blk_hi - blk_lo;
-                adler_b = (uint32_t)(((uint64_t)adler_b + (uint64_t)Lb * adler_a + T) % kAdlerMod);
-                adler_a = (adler_a + S) % kAdlerMod;
-            }
-        }
-        flushed = q_hi - gmis;
-        wave_sync();
+    __device__ __forceinline__ void flush(bool final) {
+        FlushState f = flush_ring(&io, out_al, gmis, opos, flushed, adler_a, adler_b, final, lane);
+        flushed = f.flushed;
+        adler_a = f.adler_a;
+        adler_b = f.adler_b;
     }
-
-    __device__ void make_room(uint32_t n) {
+    __device__ __forceinline__ void make_room(uint32_t n) {
         if (opos + n - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
     }
 
-    // LZ77 copy of n bytes from distance d (the copy itself, src/decompress.rs:792-829):
-    // out[opos+k] = out[opos - d + (k mod d)], every source lies before opos.
-    __device__ void copy_match(uint32_t n, uint32_t d) {
-        make_room(n);
-        wave_sync();
-        // Sources older than opos + n - kOutRing may be overwritten during the copy; they are
-        // all < flushed (make_room), so they come from global memory.
-        int64_t ring_lo = (int64_t)opos + n - kOutRing;
-        bool need_global = (int64_t)opos - (int64_t)d < ring_lo;
+    // LZ77 copy of n bytes to output position `at` from distance d (src/decompress.rs:792-829):
+    // out[at+k] = out[at - d + (k mod d)], every source lies before `at`.  `ring_top` is the
+    // highest output position that is (or is about to be) resident in the ring; sources older
+    // than ring_top - kOutRing come from global memory (they are < flushed by make_room).
+    __device__ __forceinline__ void copy_bytes(uint32_t at, uint32_t n, uint32_t d, uint32_t ring_top) {
+        int64_t ring_lo = (int64_t)ring_top - kOutRing;
+        bool need_global = (int64_t)at - (int64_t)d < ring_lo;
         if (need_global) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our own flush stores
         for (uint32_t k = lane; k < n; k += kWave) {
             uint32_t r = (d >= n) ? k : (k % d);
-            uint32_t src = opos - d + r;
+            uint32_t src = at - d + r;
             uint32_t b;
             if ((int64_t)src >= ring_lo) {
-                b = L.out_ring[(src + gmis) & kOutMask];
+                b = io.out_ring[(src + gmis) & kOutMask];
             } else {
                 // L1-bypassing load: the line may have been cached before our later stores
                 b = __hip_atomic_load(out_al + gmis + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            L.out_ring[(opos + k + gmis) & kOutMask] = (uint8_t)b;
+            io.out_ring[(at + k + gmis) & kOutMask] = (uint8_t)b;
         }
+    }
+    __device__ __forceinline__ void copy_match(uint32_t n, uint32_t d) {
+        make_room(n);
+        wave_sync();
+        copy_bytes(opos, n, d, opos + n);
         opos += n;
         wave_sync();
     }
 
     // Stored-block payload: n bytes from stream byte offset `src_byte` (src/decompress.rs:271-305).
-    __device__ void copy_stored(const uint8_t* in, uint64_t src_byte, uint32_t n) {
+    __device__ __forceinline__ void copy_stored(uint64_t src_byte, uint32_t n) {
         uint32_t done = 0;
         while (done < n) {
             uint32_t m = min(n - done, 1024u);
             make_room(m);
             wave_sync();
             for (uint32_t k = lane; k < m; k += kWave) {
-                L.out_ring[(opos + k + gmis) & kOutMask] = in[src_byte + done + k];
+                io.out_ring[(opos + k + gmis) & kOutMask] = in[src_byte + done + k];
             }
             opos += m;
             done += m;
@@ -255,37 +302,43 @@ struct Inflater {
     }
 
     // ------------------------------------------------------------------ tables
-    // CompressedBlock::build_tables, src/decompress.rs:561-606.  lens[0..320) in L.lens.
-    __device__ uint32_t build_block_tables(uint32_t hlit) {
-        if (uni(L.lens[256]) == 0) return ST_BAD_LITERAL_LENGTH_HUFFMAN_TREE;
-        if (build_table<LitlenTraits, false>(L.lit, L.lens, (int)hlit, L.lit_cb, L.lit_sorted, lane) != BUILD_OK)
+    // CompressedBlock::build_tables, src/decompress.rs:561-606.  lens[0..320) in hs->lens.
+    __device__ __forceinline__ uint32_t build_block_tables(uint32_t hlit) {
+        const uint8_t* lens = hs->lens;
+        if (uni(lens[256]) == 0) return ST_BAD_LITERAL_LENGTH_HUFFMAN_TREE;
+        if (build_table<LitlenTraits, false>(T.lit, lens, (int)hlit, T.lit_cb, T.lit_sorted, lane) != BUILD_OK)
             return ST_BAD_CODE_LENGTH_HUFFMAN_TREE;  // sic, src/decompress.rs:579
-        add_double_literals(L.lit, lane);
+        add_double_literals(T.lit, lane);
         // code of the end-of-block symbol, as the reference keeps it (eof_code/mask/bits)
-        uint32_t l256 = uni(L.lens[256]);
+        uint32_t l256 = uni(lens[256]);
         uint32_t rank = 0;
-        for (int s = lane; s < 256; s += kWave) rank += (L.lens[s] == l256) ? 1u : 0u;
+        for (int s = lane; s < 256; s += kWave) rank += (lens[s] == l256) ? 1u : 0u;
         rank = wave_sum_u32(rank);
-        uint32_t cw = uni(L.lit_cb.first[l256]) + rank;
+        uint32_t cw = uni(T.lit_cb.first[l256]) + rank;
         eof_bits = l256;
         eof_mask = (1u << l256) - 1;
         eof_code = __brev(cw) >> (32 - l256);
-        if (build_table<DistTraits, true>(L.dist, L.lens + 288, 32, L.dist_cb, L.dist_sorted, lane) != BUILD_OK)
+        if (lane == 0) {
+            T.eof[0] = eof_code;
+            T.eof[1] = eof_mask;
+            T.eof[2] = eof_bits;
+        }
+        if (build_table<DistTraits, true>(T.dist, lens + 288, 32, T.dist_cb, T.dist_sorted, lane) != BUILD_OK)
             return ST_BAD_DISTANCE_HUFFMAN_TREE;
         return ST_OK;
     }
 
-    __device__ void fill_fixed_lengths() {  // src/tables.rs:207-232
+    __device__ __forceinline__ void fill_fixed_lengths() {  // src/tables.rs:207-232
         for (int i = lane; i < 320; i += kWave) {
             uint8_t v = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
-            L.lens[i] = v;
+            hs->lens[i] = v;
         }
         wave_sync();
     }
 
-    // ------------------------------------------------------------------ the state machine
-    __device__ StreamResult run(const StreamArgs& a) {
-        // ---- set-up ----
+    // ------------------------------------------------------------------ set-up
+    __device__ __forceinline__ void init(const StreamArgs& a) {
+        in = a.in;
         uintptr_t ia = reinterpret_cast<uintptr_t>(a.in);
         mis = (uint32_t)(ia & 15);
         base16 = a.in - mis;
@@ -302,279 +355,559 @@ struct Inflater {
         flushed = 0;
         adler_a = 1;
         adler_b = 0;
-        want_adler = true;
         fixed_built = false;
+        last_block = false;
         eof_code = eof_mask = eof_bits = 0;
+        flags = a.flags;
+        serial_credit = 0;
         seek(0);
+    }
 
-        uint32_t status = ST_OK;
-        bool done = false;
-        bool last_block = false;
+    // ------------------------------------------------------------------ zlib header
+    __device__ __forceinline__ uint32_t parse_zlib_header() {  // src/decompress.rs:226-244
+        refill();
+        if (left < 16) return RC_STUCK;
+        uint32_t b0 = (uint32_t)bb & 0xFF, b1 = ((uint32_t)bb >> 8) & 0xFF;
+        if ((b0 & 0x0F) != 0x08 || (b0 & 0xF0) > 0x70 || (b1 & 0x20) != 0 || ((b0 << 8) | b1) % 31 != 0)
+            return ST_BAD_ZLIB_HEADER;
+        consume(16);
+        return RC_OK;
+    }
 
-        // ---- zlib header, src/decompress.rs:226-244 ----
-        {
+    // ------------------------------------------------------------------ block header
+    // src/decompress.rs:344-438 (+ :440-555 for dynamic blocks, :271-305 for stored payload).
+    // RC_OK: a compressed block follows (tables ready).  RC_EOB: the block is already finished
+    // (stored or empty fixed block).  RC_STUCK / status otherwise.
+    __device__ __forceinline__ uint32_t parse_block_header() {
+        refill();
+        if (left < 10) return RC_STUCK;
+        uint32_t hdr = (uint32_t)bb & 7;
+        last_block = (hdr & 1) != 0;
+        uint32_t type = hdr >> 1;
+        if (type == 0) {
+            uint32_t align = (uint32_t)((left - 3) & 7);
+            if (left < 35 + align) return RC_STUCK;
+            consume(3 + align);
             refill();
-            if (left < 16) goto stuck;
-            uint32_t b0 = (uint32_t)bb & 0xFF, b1 = ((uint32_t)bb >> 8) & 0xFF;
-            if ((b0 & 0x0F) != 0x08 || (b0 & 0xF0) > 0x70 || (b1 & 0x20) != 0 || ((b0 << 8) | b1) % 31 != 0) {
-                status = ST_BAD_ZLIB_HEADER;
-                goto finish;
-            }
-            consume(16);
-        }
-
-        for (;;) {  // one iteration per block
-            // ---- block header, src/decompress.rs:344-438 ----
-            refill();
-            if (left < 10) goto stuck;
-            {
-                uint32_t hdr = (uint32_t)bb & 7;
-                last_block = (hdr & 1) != 0;
-                uint32_t type = hdr >> 1;
-                if (type == 0) {
-                    uint32_t align = (uint32_t)((left - 3) & 7);
-                    if (left < 35 + align) goto stuck;
-                    consume(3 + align);
-                    refill();
-                    uint32_t len = (uint32_t)bb & 0xFFFF, nlen = ((uint32_t)bb >> 16) & 0xFFFF;
-                    if (nlen != (~len & 0xFFFF)) {
-                        status = ST_INVALID_UNCOMPRESSED_BLOCK_LENGTH;
-                        goto finish;
-                    }
-                    consume(32);
-                    // stored payload, src/decompress.rs:271-305
-                    uint64_t avail = left >> 3;
-                    uint32_t n = len;
-                    if ((uint64_t)n > avail) n = (uint32_t)avail;
-                    if (n > cap - opos) n = cap - opos;
-                    uint64_t src_byte = consumed_bits() >> 3;
-                    copy_stored(a.in, src_byte, n);
-                    left -= (uint64_t)n * 8;
-                    if (n < len) goto stuck;
-                    seek(consumed_bits());
-                    if (last_block) break;
-                    continue;
-                } else if (type == 1) {
-                    consume(3);
-                    if (((uint32_t)bb & 0x7F) == 0) {  // empty fixed block, :377-394
-                        consume(7);
-                        if (last_block) break;
-                        continue;
-                    }
-                    if (!fixed_built) {
-                        fill_fixed_lengths();
-                        build_block_tables(288);
-                        fixed_built = true;
-                    }
-                } else if (type == 2) {
-                    if (left < 17) goto stuck;
-                    uint32_t hlit = (((uint32_t)bb >> 3) & 31) + 257;
-                    uint32_t hdist = (((uint32_t)bb >> 8) & 31) + 1;
-                    uint32_t hclen = (((uint32_t)bb >> 13) & 15) + 4;
-                    if (hlit > 286) {
-                        status = ST_INVALID_HLIT;
-                        goto finish;
-                    }
-                    if (hdist > 30) {
-                        status = ST_INVALID_HDIST;
-                        goto finish;
-                    }
-                    consume(17);
-                    fixed_built = false;
-                    // ---- code-length code lengths, src/decompress.rs:440-477 ----
-                    refill();
-                    if (left < 3 * hclen) goto stuck;
-                    if (lane < 19) L.lens[320 - 19 + lane - 0] = 0;  // scratch: lens[301..320)
-                    wave_sync();
-                    for (uint32_t i = 0; i < hclen; i++) {
-                        refill();
-                        if (lane == 0) L.lens[301 + kClclOrder[i]] = (uint8_t)((uint32_t)bb & 7);
-                        consume(3);
-                    }
-                    wave_sync();
-                    if (build_table<ClTraits, false>(L.cl, L.lens + 301, 19, L.cl_cb, L.cl_sorted, lane) != BUILD_OK) {
-                        status = ST_BAD_CODE_LENGTH_HUFFMAN_TREE;
-                        goto finish;
-                    }
-                    // ---- literal/length + distance code lengths, src/decompress.rs:479-555 ----
-                    uint32_t total = hlit + hdist, nread = 0;
-                    // staged at lens[0..total), distance lengths moved to lens[288..) afterwards
-                    while (nread < total) {
-                        refill();
-                        if (left < 7) goto stuck;
-                        uint32_t e = uni(L.cl[(uint32_t)bb & 127]);
-                        uint32_t nb = e & 15, sym = (e >> 8) & 0xFF;
-                        if (sym <= 15) {
-                            if (lane == 0) L.lens[nread] = (uint8_t)sym;
-                            nread++;
-                            consume(nb);
-                        } else {
-                            uint32_t base_rep = sym == 18 ? 11 : 3;
-                            uint32_t extra = sym == 16 ? 2 : sym == 17 ? 3 : 7;
-                            if (left < nb + extra) goto stuck;
-                            uint32_t value = 0;
-                            if (sym == 16) {
-                                if (nread == 0) {
-                                    status = ST_INVALID_CODE_LENGTH_REPEAT;
-                                    goto finish;
-                                }
-                                wave_sync();
-                                value = uni(L.lens[nread - 1]);
-                            }
-                            uint32_t rep = (((uint32_t)bb >> nb) & ((1u << extra) - 1)) + base_rep;
-                            if (nread + rep > total) {
-                                status = ST_INVALID_CODE_LENGTH_REPEAT;
-                                goto finish;
-                            }
-                            for (uint32_t i = lane; i < rep; i += kWave) L.lens[nread + i] = (uint8_t)value;
-                            nread += rep;
-                            consume(nb + extra);
-                        }
-                    }
-                    wave_sync();
-                    {   // :541-549: distance lengths to [288, 288+hdist), zero the gaps
-                        uint8_t dl = (lane < (int)hdist) ? L.lens[hlit + lane] : 0;
-                        wave_sync();
-                        for (uint32_t i = hlit + lane; i < 288; i += kWave) L.lens[i] = 0;
-                        if (lane < 32) L.lens[288 + lane] = dl;
-                        wave_sync();
-                    }
-                    status = build_block_tables(hlit);
-                    if (status != ST_OK) goto finish;
-                } else {
-                    status = ST_INVALID_BLOCK_TYPE;
-                    goto finish;
-                }
-            }
-
-            // ---- compressed data, src/decompress.rs:611-1018 (careful-loop semantics) ----
-            for (;;) {
-                refill();
-                if (opos == cap) {  // :838-840 then the trailing EOB peek :1009-1015
-                    if (left >= 15 && ((uint32_t)bb & eof_mask) == eof_code) {
-                        consume(eof_bits);
-                        break;
-                    }
-                    goto stuck;
-                }
-                uint32_t e = uni(L.lit[(uint32_t)bb & (kLitSize - 1)]);
-                uint32_t nb = e & 15, kind = (e >> 4) & 15;
-                if (kind == K_LIT1) {
-                    if (left < nb) goto stuck;
-                    put_byte((e >> 8) & 0xFF);
-                    consume(nb);
-                    if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
-                    continue;
-                }
-                if (kind == K_LIT2) {
-                    if (left < nb) goto stuck;
-                    put_byte((e >> 8) & 0xFF);
-                    consume(nb);
-                    if (opos == cap) goto stuck;  // second literal queued, :866-876
-                    put_byte((e >> 16) & 0xFF);
-                    if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
-                    continue;
-                }
-                uint32_t len_base, len_extra, lcb;
-                if (kind == K_LONG) {  // secondary-table symbols, :886-909
-                    uint32_t sym;
-                    long_decode(L.lit_cb, L.lit_sorted, bb, sym, lcb);
-                    if (left < lcb) goto stuck;
-                    if (sym < 256) {
-                        consume(lcb);
-                        put_byte(sym);
-                        if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
-                        continue;
-                    }
-                    if (sym == 256) {
-                        consume(lcb);
-                        break;
-                    }
-                    len_base = kLenBase[sym - 257];
-                    len_extra = kLenExtra[sym - 257];
-                } else if (kind == K_EOB) {  // :912-917
-                    if (left < nb) goto stuck;
-                    consume(nb);
-                    break;
-                } else {  // K_LEN, :880-885
-                    lcb = nb;
-                    len_base = e >> 16;
-                    len_extra = (e >> 8) & 31;
-                }
-                // ---- length + distance, :919-965 ----
-                const uint64_t left0 = left;
-                uint32_t length = len_base + (uint32_t)((bb >> lcb) & ((1u << len_extra) - 1));
-                consume(lcb + len_extra);  // (the reference consumes the whole token at once;
-                refill();                  //  all of its bit checks are replayed on left0)
-                uint32_t de = uni(L.dist[(uint32_t)bb & (kDistSize - 1)]);
-                uint32_t dkind = (de >> 4) & 15;
-                uint32_t dbase, dextra, dcb;
-                if (dkind == D_DIST) {
-                    dbase = de >> 16;
-                    dextra = (de >> 8) & 15;
-                    dcb = de & 15;
-                } else if (left0 > lcb + len_extra + kDistBits) {  // :932-933
-                    if (dkind == D_INVALID) {
-                        status = ST_INVALID_DISTANCE_CODE;
-                        goto finish;
-                    }
-                    uint32_t dsym;
-                    long_decode(L.dist_cb, L.dist_sorted, bb, dsym, dcb);
-                    if (dsym >= 30) {
-                        status = ST_INVALID_DISTANCE_CODE;
-                        goto finish;
-                    }
-                    dbase = kDistBase[dsym];
-                    dextra = kDistExtra[dsym];
-                } else {
-                    goto stuck;
-                }
-                uint32_t total_bits = lcb + len_extra + dcb + dextra;
-                uint32_t dist = dbase + (uint32_t)((bb >> dcb) & ((1u << dextra) - 1));
-                if (left0 < total_bits) goto stuck;
-                if (dist > opos) {
-                    status = ST_DISTANCE_TOO_FAR_BACK;
-                    goto finish;
-                }
-                consume(dcb + dextra);
-                uint32_t n = min(length, cap - opos);
-                copy_match(n, dist);
-                if (n < length) goto stuck;  // remainder queued, output full
-            }
-            if (last_block) break;
-        }
-
-        // ---- checksum, src/decompress.rs:306-326 ----
-        {
-            refill();
-            uint32_t align = (uint32_t)(left & 7);
-            if (left < 32 + align) goto stuck;
-            consume(align);
-            refill();
-            uint32_t stored = __builtin_bswap32((uint32_t)bb);
+            uint32_t len = (uint32_t)bb & 0xFFFF, nlen = ((uint32_t)bb >> 16) & 0xFFFF;
+            if (nlen != (~len & 0xFFFF)) return ST_INVALID_UNCOMPRESSED_BLOCK_LENGTH;
             consume(32);
-            flush(true);
-            uint32_t adler = (adler_b << 16) | adler_a;
-            if (!(a.flags & 1u) && stored != adler) {
-                status = ST_WRONG_CHECKSUM;
-                goto finish;
-            }
-            done = true;
-            goto finish;
+            uint64_t avail = left >> 3;
+            uint32_t n = len;
+            if ((uint64_t)n > avail) n = (uint32_t)avail;
+            if (n > cap - opos) n = cap - opos;
+            uint64_t src_byte = consumed_bits() >> 3;
+            copy_stored(src_byte, n);
+            left -= (uint64_t)n * 8;
+            if (n < len) return RC_STUCK;
+            seek(consumed_bits());
+            return RC_EOB;
         }
+        if (type == 1) {
+            consume(3);
+            if (((uint32_t)bb & 0x7F) == 0) {  // empty fixed block, :377-394
+                consume(7);
+                return RC_EOB;
+            }
+            if (!fixed_built) {
+                fill_fixed_lengths();
+                build_block_tables(288);
+                fixed_built = true;
+            }
+            return RC_OK;
+        }
+        if (type == 3) return ST_INVALID_BLOCK_TYPE;
+        // ---- dynamic block ----
+        if (left < 17) return RC_STUCK;
+        uint32_t hlit = (((uint32_t)bb >> 3) & 31) + 257;
+        uint32_t hdist = (((uint32_t)bb >> 8) & 31) + 1;
+        uint32_t hclen = (((uint32_t)bb >> 13) & 15) + 4;
+        if (hlit > 286) return ST_INVALID_HLIT;
+        if (hdist > 30) return ST_INVALID_HDIST;
+        consume(17);
+        fixed_built = false;
+        // code-length code lengths, src/decompress.rs:440-477 (scratch: lens[301..320))
+        refill();
+        if (left < 3 * hclen) return RC_STUCK;
+        uint8_t* lens = hs->lens;
+        if (lane < 19) lens[301 + lane] = 0;
+        wave_sync();
+        for (uint32_t i = 0; i < hclen; i++) {
+            refill();
+            if (lane == 0) lens[301 + kClclOrder[i]] = (uint8_t)((uint32_t)bb & 7);
+            consume(3);
+        }
+        wave_sync();
+        if (build_table<ClTraits, false>(hs->cl, lens + 301, 19, hs->cl_cb, hs->cl_sorted, lane) != BUILD_OK)
+            return ST_BAD_CODE_LENGTH_HUFFMAN_TREE;
+        // literal/length + distance code lengths, src/decompress.rs:479-555
+        uint32_t total = hlit + hdist, nread = 0;
+        while (nread < total) {
+            refill();
+            if (left < 7) return RC_STUCK;
+            uint32_t e = uni(hs->cl[(uint32_t)bb & 127]);
+            uint32_t nb = e & 15, sym = (e >> 8) & 0xFF;
+            if (sym <= 15) {
+                if (lane == 0) lens[nread] = (uint8_t)sym;
+                nread++;
+                consume(nb);
+            } else {
+                uint32_t base_rep = sym == 18 ? 11 : 3;
+                uint32_t extra = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+                if (left < nb + extra) return RC_STUCK;
+                uint32_t value = 0;
+                if (sym == 16) {
+                    if (nread == 0) return ST_INVALID_CODE_LENGTH_REPEAT;
+                    wave_sync();
+                    value = uni(lens[nread - 1]);
+                }
+                uint32_t rep = (((uint32_t)bb >> nb) & ((1u << extra) - 1)) + base_rep;
+                if (nread + rep > total) return ST_INVALID_CODE_LENGTH_REPEAT;
+                for (uint32_t i = lane; i < rep; i += kWave) lens[nread + i] = (uint8_t)value;
+                nread += rep;
+                consume(nb + extra);
+            }
+        }
+        wave_sync();
+        {   // :541-549: distance lengths to [288, 288+hdist), zero the gaps
+            uint8_t dl = (lane < (int)hdist) ? lens[hlit + lane] : 0;
+            wave_sync();
+            for (uint32_t i = hlit + lane; i < 288; i += kWave) lens[i] = 0;
+            if (lane < 32) lens[288 + lane] = dl;
+            wave_sync();
+        }
+        return build_block_tables(hlit);
+    }
 
-    stuck:
-        // src/decompress.rs:1126-1139: not done and no error -> OutputTooLarge if the slot is
-        // full, InsufficientInput otherwise.
-        status = (opos == cap) ? ST_OUTPUT_TOO_LARGE : ST_INSUFFICIENT_INPUT;
-    finish:
-        (void)done;
+    // ------------------------------------------------------------------ serial decoder
+    // One symbol of a compressed block with the reference's careful-loop semantics
+    // (src/decompress.rs:836-1015).  RC_OK / RC_EOB / RC_STUCK / status.
+    __device__ __forceinline__ uint32_t serial_token() {
+        refill();
+        if (opos == cap) {  // :838-840 then the trailing end-of-block peek :1009-1015
+            if (left >= 15 && ((uint32_t)bb & eof_mask) == eof_code) {
+                consume(eof_bits);
+                return RC_EOB;
+            }
+            return RC_STUCK;
+        }
+        uint32_t e = uni(T.lit[(uint32_t)bb & (kLitSize - 1)]);
+        uint32_t nb = e & 15, kind = (e >> 4) & 15;
+        if (kind == K_LIT1) {
+            if (left < nb) return RC_STUCK;
+            put_byte((e >> 8) & 0xFF);
+            consume(nb);
+            if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
+            return RC_OK;
+        }
+        if (kind == K_LIT2) {
+            if (left < nb) return RC_STUCK;
+            put_byte((e >> 8) & 0xFF);
+            consume(nb);
+            if (opos == cap) return RC_STUCK;  // second literal queued, :866-876
+            put_byte((e >> 16) & 0xFF);
+            if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
+            return RC_OK;
+        }
+        uint32_t len_base, len_extra, lcb;
+        if (kind == K_LONG) {  // secondary-table symbols, :886-909
+            uint32_t sym;
+            long_decode(T.lit_cb, T.lit_sorted, bb, sym, lcb);
+            if (left < lcb) return RC_STUCK;
+            if (sym < 256) {
+                consume(lcb);
+                put_byte(sym);
+                if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
+                return RC_OK;
+            }
+            if (sym == 256) {
+                consume(lcb);
+                return RC_EOB;
+            }
+            len_base = kLenBase[sym - 257];
+            len_extra = kLenExtra[sym - 257];
+        } else if (kind == K_EOB) {  // :912-917
+            if (left < nb) return RC_STUCK;
+            consume(nb);
+            return RC_EOB;
+        } else {  // K_LEN, :880-885
+            lcb = nb;
+            len_base = e >> 16;
+            len_extra = (e >> 8) & 31;
+        }
+        // ---- length + distance, :919-965 ----
+        const uint64_t left0 = left;
+        uint32_t length = len_base + (uint32_t)((bb >> lcb) & ((1u << len_extra) - 1));
+        consume(lcb + len_extra);  // (the reference consumes the whole token at once;
+        refill();                  //  all of its bit checks are replayed on left0)
+        uint32_t de = uni(T.dist[(uint32_t)bb & (kDistSize - 1)]);
+        uint32_t dkind = (de >> 4) & 15;
+        uint32_t dbase, dextra, dcb;
+        if (dkind == D_DIST) {
+            dbase = de >> 16;
+            dextra = (de >> 8) & 15;
+            dcb = de & 15;
+        } else if (left0 > lcb + len_extra + kDistBits) {  // :932-933
+            if (dkind == D_INVALID) return ST_INVALID_DISTANCE_CODE;
+            uint32_t dsym;
+            long_decode(T.dist_cb, T.dist_sorted, bb, dsym, dcb);
+            if (dsym >= 30) return ST_INVALID_DISTANCE_CODE;
+            dbase = kDistBase[dsym];
+            dextra = kDistExtra[dsym];
+        } else {
+            return RC_STUCK;
+        }
+        uint32_t total_bits = lcb + len_extra + dcb + dextra;
+        uint32_t dist = dbase + (uint32_t)((bb >> dcb) & ((1u << dextra) - 1));
+        if (left0 < total_bits) return RC_STUCK;
+        if (dist > opos) return ST_DISTANCE_TOO_FAR_BACK;
+        consume(dcb + dextra);
+        uint32_t n = min(length, cap - opos);
+        copy_match(n, dist);
+        if (n < length) return RC_STUCK;  // remainder queued, output full
+        return RC_OK;
+    }
+
+    // ------------------------------------------------------------------ tile decoder
+    // Decodes up to 64 x 64 stream bits of the current block in parallel.  `progress` = stream
+    // bits consumed.  Returns RC_OK, RC_EOB (block finished inside the tile) or a status.
+    // Everything the tile cannot prove harmless (codes beyond the primary tables, invalid or
+    // truncated tokens, a full slot, too many matches) ends the tile in front of the offending
+    // symbol; the serial decoder then deals with exactly that symbol.
+    __device__ __forceinline__ uint32_t tile_step(uint32_t& progress) {
+        progress = 0;
+        // keep the un-flushed part of the ring small so a whole tile fits
+        if (opos - flushed > 1024) flush(false);
+        const uint64_t P = consumed_bits();
+        const uint64_t wbit = P + (uint64_t)mis * 8;
+        const uint32_t d0 = (uint32_t)(wbit >> 5);
+        const uint32_t sh = (uint32_t)wbit & 31;
+        ensure_dw(d0);
+        ensure_dw(d0 + 2 * kWave + 4);
+        // this lane's 64 bits + 64 bits of look-ahead, normalised to start at bit 0 of w0
+        uint32_t r0 = io.in_ring[(d0 + 2 * lane + 0) & (kInRingDw - 1)];
+        uint32_t r1 = io.in_ring[(d0 + 2 * lane + 1) & (kInRingDw - 1)];
+        uint32_t r2 = io.in_ring[(d0 + 2 * lane + 2) & (kInRingDw - 1)];
+        uint32_t r3 = io.in_ring[(d0 + 2 * lane + 3) & (kInRingDw - 1)];
+        uint32_t r4 = io.in_ring[(d0 + 2 * lane + 4) & (kInRingDw - 1)];
+        const uint32_t w0 = __builtin_amdgcn_alignbit(r1, r0, sh);
+        const uint32_t w1 = __builtin_amdgcn_alignbit(r2, r1, sh);
+        const uint32_t w2 = __builtin_amdgcn_alignbit(r3, r2, sh);
+        const uint32_t w3 = __builtin_amdgcn_alignbit(r4, r3, sh);
+        // stream bits available from this lane's chunk start (may be <= 0 past the end)
+        int64_t la64 = (int64_t)left - (int64_t)kTileBits * lane;
+        const int32_t la = la64 > (1 << 20) ? (1 << 20) : (la64 < -1 ? -1 : (int32_t)la64);
+
+        auto bits32 = [&](uint32_t p) -> uint32_t {  // 32 stream bits starting at chunk bit p (< 96)
+            uint32_t lo = p < 32 ? w0 : (p < 64 ? w1 : w2);
+            uint32_t hi = p < 32 ? w1 : (p < 64 ? w2 : w3);
+            return __builtin_amdgcn_alignbit(hi, lo, p & 31);
+        };
+        // Decodes the token at chunk bit p.  kind: 0 literal(s), 1 match, 2 end-of-block, 3 bad.
+        // adv1: bits of the first symbol; adv: bits of the whole table entry / token.
+        auto token = [&](uint32_t p, uint32_t& kind, uint32_t& adv1, uint32_t& adv) {
+            uint32_t e = T.lit[bits32(p) & (kLitSize - 1)];
+            uint32_t nb = e & 15, k = (e >> 4) & 15;
+            if (k <= K_LIT2) {
+                kind = 0;
+                adv1 = e >> 24;
+                adv = nb;
+            } else if (k == K_LEN) {
+                uint32_t t = nb + ((e >> 8) & 31);
+                uint32_t de = T.dist[bits32(p + t) & (kDistSize - 1)];
+                kind = (((de >> 4) & 15) == D_DIST) ? 1 : 3;
+                adv = t + (de & 15) + ((de >> 8) & 15);
+                adv1 = adv;
+            } else if (k == K_EOB) {
+                kind = 2;
+                adv = adv1 = nb;
+            } else {
+                kind = 3;
+                adv = adv1 = 0;
+            }
+            if ((int32_t)(p + adv) > la) kind = 3;  // token (or literal pair) not fully inside the input
+        };
+
+        // ---- pass 1: speculative chain from chunk bit 0 (lane 0's start is a real boundary) ----
+        uint64_t mask = 0, mmask = 0;   // symbol starts / match starts inside [start, 64)
+        uint32_t start = 0, endp = 0;   // chain start, chain end (>= 64 when it left the chunk)
+        uint32_t stop = 0, stop_pos = 0, stop_nb = 0;  // 0 none, 1 end-of-block, 2 bad
+        {
+            uint32_t p = 0;
+            while (p < (uint32_t)kTileBits) {
+                uint32_t kind, a1, a;
+                token(p, kind, a1, a);
+                if (kind == 0) {
+                    mask |= 1ull << p;
+                    if (a != a1 && p + a1 < (uint32_t)kTileBits) {
+                        mask |= 1ull << (p + a1);
+                        p += a;
+                    } else {
+                        p += a1;
+                    }
+                } else if (kind == 1) {
+                    mask |= 1ull << p;
+                    mmask |= 1ull << p;
+                    p += a;
+                } else {
+                    stop = kind == 2 ? 1 : 2;
+                    stop_pos = p;
+                    stop_nb = a;
+                    break;
+                }
+            }
+            endp = p;
+        }
+        // ---- synchronisation: hand every lane the real start of its chain ----
+        // A lane whose predecessor's chain currently stops (end-of-block / bad token, possibly on
+        // a still-speculative chain) has no start to take over and sits the iteration out.  At
+        // exit every lane up to the first stop holds the true chain (induction from lane 0).
+        bool converged = false;
+        for (int iter = 0; iter < 2 * kWave; iter++) {
+            uint32_t prev_end = __shfl_up(endp, 1, kWave);
+            uint32_t prev_stop = __shfl_up(stop, 1, kWave);
+            uint32_t in_start = prev_end - kTileBits;
+            bool need = lane != 0 && prev_stop == 0 && in_start != start;
+            if (!__any(need)) {
+                converged = true;
+                break;
+            }
+            if (need) {
+                // follow the chain from in_start one symbol at a time until it meets the old
+                // chain, leaves the chunk or stops
+                uint64_t nm = 0, nmm = 0;
+                uint32_t p = in_start;
+                for (;;) {
+                    if (p >= (uint32_t)kTileBits) {
+                        mask = nm;
+                        mmask = nmm;
+                        stop = 0;
+                        endp = p;
+                        break;
+                    }
+                    if ((mask >> p) & 1) {  // merged: the rest of the old chain is right
+                        uint64_t keep = ~((1ull << p) - 1);
+                        mask = nm | (mask & keep);
+                        mmask = nmm | (mmask & keep);
+                        break;
+                    }
+                    uint32_t kind, a1, a;
+                    token(p, kind, a1, a);
+                    if (kind <= 1) {
+                        nm |= 1ull << p;
+                        if (kind == 1) nmm |= 1ull << p;
+                        p += a1;
+                    } else {
+                        mask = nm;
+                        mmask = nmm;
+                        stop = kind == 2 ? 1 : 2;
+                        stop_pos = p;
+                        stop_nb = a;
+                        endp = p;
+                        break;
+                    }
+                }
+                start = in_start;
+            }
+        }
+        if (!converged) return RC_OK;  // pathological input: the serial decoder decides
+        const uint64_t stopped = __ballot(stop != 0);
+        const int stop_lane = stopped ? __ffsll((unsigned long long)stopped) - 1 : kWave;
+        const bool live = lane <= stop_lane;
+        const bool dead = !live;
+        (void)dead;
+
+        // ---- output bytes per lane: one per symbol + (length - 1) per match ----
+        uint32_t count = live ? (uint32_t)__popcll(mask) : 0;
+        uint32_t mcount = live ? (uint32_t)__popcll(mmask) : 0;
+        if (mcount) {
+            uint64_t mm = mmask;
+            while (mm) {
+                uint32_t p = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                uint32_t e = T.lit[bits32(p) & (kLitSize - 1)];
+                uint32_t lcb = e & 15, lex = (e >> 8) & 31;
+                uint32_t length = (e >> 16) + ((bits32(p + lcb)) & ((1u << lex) - 1));
+                count += length - 1;
+            }
+        }
+        // exclusive prefix sums (bytes in the low 20 bits, matches above)
+        uint32_t packed = count | (mcount << 20);
+        uint32_t incl = packed;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            uint32_t y = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += y;
+        }
+        uint32_t excl = incl - packed;
+        const uint32_t obase = excl & 0xFFFFF, mbase = excl >> 20;
+        // lanes that would overflow the slot, the ring or the match list end the tile early
+        const uint32_t room = min(cap - opos, (uint32_t)(kOutRing - kFlushSlack - 16) - (opos - flushed));
+        const bool over = live && (obase + count > room || mbase + mcount > (uint32_t)kMaxMatches);
+        const uint64_t over_mask = __ballot(over);
+        const int cut_lane = over_mask ? __ffsll((unsigned long long)over_mask) - 1 : kWave;
+        const bool emit = live && lane < cut_lane;
+        // last emitting lane decides where the stream continues
+        const int last_lane = min(min(stop_lane, cut_lane - 1), kWave - 1);
+        if (last_lane < 0) return RC_OK;  // nothing fits: serial decides
+        const uint32_t total_packed = __shfl(incl, last_lane, kWave);
+        const uint32_t total = total_packed & 0xFFFFF, nmatch = total_packed >> 20;
+
+        // ---- emit literals, list matches ----
+        wave_sync();
+        if (emit) {
+            uint64_t m = mask;
+            uint32_t opo = opos + obase + gmis;
+            uint32_t mi = mbase;
+            while (m) {
+                uint32_t p = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t e = T.lit[bits32(p) & (kLitSize - 1)];
+                uint32_t k = (e >> 4) & 15;
+                if (k <= K_LIT2) {
+                    io.out_ring[opo & kOutMask] = (uint8_t)(e >> 8);
+                    opo++;
+                    uint32_t n1 = e >> 24;
+                    if (k == K_LIT2 && p + n1 < (uint32_t)kTileBits) {
+                        io.out_ring[opo & kOutMask] = (uint8_t)(e >> 16);
+                        opo++;
+                        m &= ~(1ull << (p + n1));
+                    }
+                } else {  // match
+                    uint32_t lcb = e & 15, lex = (e >> 8) & 31;
+                    uint32_t length = (e >> 16) + (bits32(p + lcb) & ((1u << lex) - 1));
+                    uint32_t dv = bits32(p + lcb + lex);
+                    uint32_t de = T.dist[dv & (kDistSize - 1)];
+                    uint32_t dcb = de & 15, dex = (de >> 8) & 15;
+                    uint32_t dist = (de >> 16) + ((dv >> dcb) & ((1u << dex) - 1));
+                    io.mlist[2 * mi] = (opo - gmis - opos) | (length << 16);
+                    io.mlist[2 * mi + 1] = dist;
+                    mi++;
+                    opo += length;
+                }
+            }
+        }
+        wave_sync();
+        // ---- replay matches in stream order (sources are final by then) ----
+        for (uint32_t j = 0; j < nmatch; j++) {
+            uint32_t m0 = uni(io.mlist[2 * j]), dist = uni(io.mlist[2 * j + 1]);
+            uint32_t at = opos + (m0 & 0xFFFF), length = m0 >> 16;
+            if (dist > at) return ST_DISTANCE_TOO_FAR_BACK;  // src/decompress.rs:782
+            copy_bytes(at, length, dist, opos + total);
+            wave_sync();
+        }
+#ifdef FDH_DEBUG_TILES
+        {
+            uint32_t slot = g_dbg_n;  // single-stream debugging only
+            uint32_t* d = g_dbg + 8 + slot * 264;
+            if (slot < 200) {
+                if (lane == 0) {
+                    d[0] = (uint32_t)P; d[1] = total; d[2] = (uint32_t)stop_lane; d[3] = (uint32_t)cut_lane;
+                    d[4] = (uint32_t)last_lane; d[5] = opos; d[6] = flushed; d[7] = (uint32_t)left;
+                }
+                d[8 + lane * 4 + 0] = start; d[8 + lane * 4 + 1] = endp; d[8 + lane * 4 + 2] = count | (stop << 16) | ((dead ? 1u : 0u) << 20);
+                d[8 + lane * 4 + 3] = obase;
+            }
+            wave_sync();
+            if (lane == 0) g_dbg_n = slot + 1;
+        }
+#endif
+        opos += total;
+        // ---- advance the bit reader ----
+        uint32_t rc = RC_OK;
+        uint32_t used;  // bits consumed relative to P
+        if (last_lane == stop_lane) {
+            uint32_t sp = __shfl(stop_pos, last_lane, kWave), sn = __shfl(stop_nb, last_lane, kWave);
+            uint32_t sk = __shfl(stop, last_lane, kWave);
+            used = (uint32_t)last_lane * kTileBits + sp;
+            // With the slot exactly full the reference only accepts the real end-of-block code
+            // (src/decompress.rs:1009-1015; fixed symbols 286/287 do not qualify): serial_token
+            // owns that rule, so the end-of-block symbol is left to it.
+            if (sk == 1 && opos != cap) {
+                used += sn;
+                rc = RC_EOB;
+            }
+        } else if (cut_lane < kWave) {
+            used = (uint32_t)cut_lane * kTileBits + __shfl(start, cut_lane, kWave);
+        } else {
+            used = (uint32_t)(kWave - 1) * kTileBits + __shfl(endp, kWave - 1, kWave);
+        }
+        left -= used;
+        progress = used;
+        seek(P + used);
+        return rc;
+    }
+
+    // ------------------------------------------------------------------ compressed block data
+    template <bool TILES>
+    __device__ __forceinline__ uint32_t decode_block_data() {
+        for (;;) {
+            if (TILES && serial_credit == 0 && opos < cap) {
+                uint32_t progress;
+                uint32_t rc = tile_step(progress);
+                if (rc != RC_OK) return rc;
+                // a tile that got stuck early: let the serial decoder clear the obstacle
+                if (progress < 16 * kTileBits) serial_credit = progress == 0 ? 4 : 1;
+                if (progress) continue;
+            }
+            uint32_t rc = serial_token();
+            if (rc != RC_OK) return rc;
+            if (serial_credit) serial_credit--;
+        }
+    }
+
+    // ------------------------------------------------------------------ checksum
+    __device__ __forceinline__ uint32_t finish_checksum() {  // src/decompress.rs:306-326
+        refill();
+        uint32_t align = (uint32_t)(left & 7);
+        if (left < 32 + align) return RC_STUCK;
+        consume(align);
+        refill();
+        uint32_t stored = __builtin_bswap32((uint32_t)bb);
+        consume(32);
         flush(true);
+        uint32_t adler = (adler_b << 16) | adler_a;
+        if (!(flags & 1u) && stored != adler) return ST_WRONG_CHECKSUM;
+        return RC_OK;
+    }
+
+    __device__ __forceinline__ StreamResult finish(uint32_t rc) {
         StreamResult r;
-        r.status = status;
+        r.ambiguous = false;
+        if (rc == RC_STUCK) {
+            // src/decompress.rs:1126-1139: not done and no error -> OutputTooLarge if the slot is
+            // full, InsufficientInput otherwise.
+            r.status = (opos == cap) ? ST_OUTPUT_TOO_LARGE : ST_INSUFFICIENT_INPUT;
+            r.ambiguous = left < 128;
+        } else {
+            r.status = rc;
+        }
+        flush(true);
         r.out_len = opos;
         r.adler = (adler_b << 16) | adler_a;
         return r;
+    }
+
+    // Whole stream.  START_IN_BLOCK: the zlib header and the (final, dynamic) block header were
+    // recognised by the caller and the tables are in place.
+    template <bool TILES, bool START_IN_BLOCK>
+    __device__ __forceinline__ StreamResult run() {
+        uint32_t rc;
+        if (!START_IN_BLOCK) {
+            rc = parse_zlib_header();
+            if (rc != RC_OK) return finish(rc);
+        }
+        for (;;) {
+            if (!START_IN_BLOCK) {
+                rc = parse_block_header();
+                if (rc == RC_OK) rc = decode_block_data<TILES>();
+            } else {
+                rc = decode_block_data<TILES>();
+            }
+            if (rc != RC_EOB) return finish(rc);
+            if (last_block) break;
+        }
+        return finish(finish_checksum());
     }
 };
 

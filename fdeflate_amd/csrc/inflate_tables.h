@@ -70,7 +70,7 @@ enum BuildResult : int { BUILD_OK = 0, BUILD_INCOMPLETE = 1 };
 // Builds `table` (1 << Traits::kBits entries, LDS) from `lens[0..n)` (LDS).  All 64 lanes call.
 // IS_DIST adds the two distance-only cases of src/huffman.rs:40-59.
 template <class Traits, bool IS_DIST>
-__device__ int build_table(uint32_t* table, const uint8_t* lens, int n, CodeBook& cb,
+__device__ __forceinline__ int build_table(uint32_t* table, const uint8_t* lens, int n, CodeBook& cb,
                            uint16_t* sorted, int lane) {
     constexpr int PB = Traits::kBits;
     constexpr int TSIZE = 1 << PB;
@@ -156,7 +156,7 @@ __device__ int build_table(uint32_t* table, const uint8_t* lens, int n, CodeBook
 
 // Second pass for the litlen table: turn single-literal entries into double-literal entries
 // wherever the next symbol is also a literal and both codes fit in kLitBits bits.
-__device__ inline void add_double_literals(uint32_t* table, int lane) {
+__device__ __forceinline__ void add_double_literals(uint32_t* table, int lane) {
     for (int idx = lane; idx < kLitSize; idx += kWave) {
         uint32_t e1 = table[idx];
         uint32_t k1 = (e1 >> 4) & 15;
@@ -175,7 +175,7 @@ __device__ inline void add_double_literals(uint32_t* table, int lane) {
 
 // Canonical decode of a code longer than the primary index (the reference's secondary
 // tables, src/huffman.rs:138-181).  `bits` holds >= 15 stream bits, LSB first.  Uniform.
-__device__ inline void long_decode(const CodeBook& cb, const uint16_t* sorted, uint64_t bits,
+__device__ __forceinline__ void long_decode(const CodeBook& cb, const uint16_t* sorted, uint64_t bits,
                                    uint32_t& sym, uint32_t& nbits) {
     uint32_t code = 0, first = 0, index = 0;
     sym = 0;

@@ -63,6 +63,8 @@ enum {
 /* ---- flags -------------------------------------------------------------------------- */
 #define FDH_FLAG_IGNORE_ADLER32 0x1u /* Decompressor::ignore_adler32, src/decompress.rs:154 */
 #define FDH_FLAG_SERIAL_ONLY    0x2u /* debug/A-B: force the per-symbol wave-serial decoder */
+#define FDH_FLAG_GENERAL_ONLY   0x4u /* debug/A-B: skip the shared-table kernel */
+#define FDH_FLAG_NO_RECHECK     0x8u /* tests: do not re-derive non-Ok results serially */
 
 /*
  * fdh_inflate_batch -- one-shot decode of `n` independent zlib streams, one wavefront each.

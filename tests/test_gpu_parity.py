@@ -126,6 +126,22 @@ def test_valid_streams_all_block_types(harness):
     harness.assert_inflate_parity(names, blobs, caps)
 
 
+def test_valid_streams_every_decoder_variant(harness):
+    """The same valid streams through each decoder on its own: shared-table + tiles without the
+    serial re-check (8), general kernel with tiles (4|8), serial only (2).  With the re-check off
+    a tile-decoder bug cannot hide behind the exact serial path."""
+    names, blobs, caps = [], [], []
+    for name, comp, raw in streams.valid_streams():
+        if name == "fixed_sym286_is_eob":
+            continue
+        for c in (len(raw), len(raw) + 100):
+            names.append("%s@%d" % (name, c))
+            blobs.append(comp)
+            caps.append(c)
+    for flags in (8, 4 | 8, 2):
+        harness.assert_inflate_parity(names, blobs, caps, flags=flags)
+
+
 def test_valid_streams_ignore_adler(harness):
     names, blobs, caps = [], [], []
     for name, comp, raw in streams.valid_streams():
