@@ -28,6 +28,8 @@ FLAG_IGNORE_ADLER32 = 1
 FLAG_SERIAL_ONLY = 2
 FLAG_GENERAL_ONLY = 4
 FLAG_NO_RECHECK = 8
+FLAG_FORCE_LANES = 16
+FLAG_NO_LANES = 32
 
 
 class DecompressionError(Exception):

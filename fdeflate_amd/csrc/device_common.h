@@ -46,6 +46,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// c ? a : b as one v_cndmask.  Opaque to the optimiser on purpose: hipcc otherwise rewrites
+// chains of selects over a few registers into an indexed load from a scratch-memory table.
+__device__ __forceinline__ uint32_t vsel(bool c, uint32_t a, uint32_t b) {
+    uint32_t r;
+    uint64_t m = __ballot(c);
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return ((uint64_t)1 << lane) - 1; }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {

@@ -18,6 +18,7 @@
 // double-literal table at the very end of a truncated input, and all hard errors, are re-derived
 // by the symbol-serial decoder, whose pairing is the reference's (DESIGN.md "error parity").
 #include "inflate_stream.h"
+#include "inflate_lanes.h"
 
 namespace fdh {
 
@@ -27,6 +28,7 @@ constexpr uint32_t kPending = 0xFFFFFFFFu;         // not decoded yet, tiles all
 constexpr uint32_t kPendingSerial = 0xFFFFFFFEu;   // not decoded yet, serial decoder only
 constexpr uint32_t kCanonBits = 53 * 8 + 5;        // ultrafast.rs:87-88
 constexpr int kCanonWaves = 8;
+constexpr uint64_t kLaneMinStreams = ~0ull;  // opt-in only (FDH_FLAG_FORCE_LANES): 1 wave/SIMD at 64 Ki streams is no win
 
 struct CanonTables {
     uint32_t lit[kLitSize];
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
     __syncthreads();
     const uint64_t sid = (uint64_t)blockIdx.x * kCanonWaves + wid;
     if (sid >= a.n) return;
+    if (a.only_pending && a.status[sid] != kPending) return;  // the lane kernel already finished it
     const StreamArgs s = stream_args(a, sid);
     Inflater inf(lds.tables, lds.io[wid], nullptr, lane);
     inf.init(s);
@@ -186,6 +189,18 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
     }
 }
 
+// Dense batches of canonical streams: one stream per lane (inflate_lanes.h).
+__global__ __launch_bounds__(kLaneBlock) void inflate_lanes_kernel(LaneArgs a) {
+    __shared__ LaneLds lds;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit);
+        uint4* dst = reinterpret_cast<uint4*>(lds.lit);
+        for (int i = threadIdx.x; i < kLitSize / 4; i += kLaneBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    lanes_decode(a, lds);
+}
+
 // Parses the canonical prefix once per device and keeps the resulting tables in g_canon.
 __global__ __launch_bounds__(kWave) void canon_build_kernel() {
     __shared__ GeneralLds lds;
@@ -217,6 +232,9 @@ __global__ __launch_bounds__(kWave) void canon_build_kernel() {
         g_canon.eof[2] = inf.eof_bits;
         g_canon.eof[3] = 0;
         bool ok = rc == RC_OK && inf.last_block && inf.consumed_bits() == kCanonBits;
+        // the lane kernel relies on the prefix declaring exactly one distance code: 1 bit, '0' =
+        // distance 1 (HDIST = 1, reference src/lib.rs:8 "no distance codes except for RLE of zeros")
+        ok = ok && lds.tables.dist[0] == DistTraits::entry(0, 1) && ((lds.tables.dist[1] >> 4) & 15) == D_INVALID;
         g_canon.status = ok ? (uint32_t)ST_OK : (rc == RC_OK ? 0xBADu : rc);
     }
 }
@@ -257,6 +275,10 @@ extern "C" int fdh_debug_read(uint32_t* host, uint32_t nwords, int reset) {
 }
 #endif
 
+// device address of g_canon, looked up once per device by fdh_launch_canon_build (the lookup
+// synchronises, so it must stay off the launch path)
+static fdh::CanonTables* g_canon_dev[64] = {};
+
 extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status) {
     hipLaunchKernelGGL(fdh::canon_build_kernel, dim3(1), dim3(fdh::kWave), 0, stream);
     hipError_t e = hipGetLastError();
@@ -267,6 +289,9 @@ extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status)
     e = hipGetSymbolAddress(reinterpret_cast<void**>(&dev), HIP_SYMBOL(fdh::g_canon));
     if (e != hipSuccess) return (int)e;
     e = hipMemcpy(host_status, &dev->status, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    int ordinal = 0;
+    if (e == hipSuccess) e = hipGetDevice(&ordinal);
+    if (e == hipSuccess && ordinal >= 0 && ordinal < 64) g_canon_dev[ordinal] = dev;
     return (int)e;
 }
 
@@ -279,9 +304,28 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
         return (int)hipGetLastError();
     }
+    hipError_t e;
+    // Dense batches first go through the stream-per-lane kernel; it finishes the canonical
+    // streams that decode cleanly and leaves everything else PENDING.
+    const bool lanes = (flags & 16u) || (n >= fdh::kLaneMinStreams && !(flags & 32u));
+    if (lanes) {
+        int ordinal = 0;
+        e = hipGetDevice(&ordinal);
+        if (e != hipSuccess) return (int)e;
+        fdh::CanonTables* canon = (ordinal >= 0 && ordinal < 64) ? g_canon_dev[ordinal] : nullptr;
+        if (!canon) return (int)hipErrorNotInitialized;
+        fdh::LaneArgs la{in, in_off, out, out_off, out_len, status, adler, n, flags,
+                         canon->lit, canon->dist, canon->hdr, fdh::kCanonBits, fdh::kPending};
+        unsigned lblocks = (unsigned)((n + fdh::kLaneBlock - 1) / fdh::kLaneBlock);
+        hipLaunchKernelGGL(fdh::inflate_lanes_kernel, dim3(lblocks), dim3(fdh::kLaneBlock), 0, stream, la);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        a.only_pending = 1;
+        if (flags & 64u) return 0;  // debug: lane kernel only (PENDING streams stay undecoded)
+    }
     unsigned blocks = (unsigned)((n + fdh::kCanonWaves - 1) / fdh::kCanonWaves);
     hipLaunchKernelGGL(fdh::inflate_canon_kernel, dim3(blocks), dim3(fdh::kCanonWaves * fdh::kWave), 0, stream, a);
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     a.only_pending = 1;
     hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);

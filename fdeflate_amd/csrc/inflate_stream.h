@@ -89,7 +89,7 @@ __device__ uint32_t g_dbg_n;
 struct FlushState {
     uint32_t flushed, adler_a, adler_b;
 };
-__device__ __attribute__((noinline)) FlushState flush_ring(WaveIo* iop, uint8_t* out_al, uint32_t gmis,
+__device__ __forceinline__ FlushState flush_ring(WaveIo* iop, uint8_t* out_al, uint32_t gmis,
                                                            uint32_t opos, uint32_t flushed, uint32_t adler_a,
                                                            uint32_t adler_b, bool final, int lane) {
     WaveIo& io = *iop;
@@ -277,8 +277,7 @@ struct Inflater {
             io.out_ring[(at + k + gmis) & kOutMask] = (uint8_t)b;
         }
     }
-    __device__ __forceinline__ void copy_match(uint32_t n, uint32_t d) {
-        make_room(n);
+    __device__ __forceinline__ void copy_match(uint32_t n, uint32_t d) {  // caller made room
         wave_sync();
         copy_bytes(opos, n, d, opos + n);
         opos += n;
@@ -483,6 +482,8 @@ struct Inflater {
     // One symbol of a compressed block with the reference's careful-loop semantics
     // (src/decompress.rs:836-1015).  RC_OK / RC_EOB / RC_STUCK / status.
     __device__ __forceinline__ uint32_t serial_token() {
+        // room for any single token (<= 258 bytes) so nothing below has to flush
+        if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack - 264)) flush(false);
         refill();
         if (opos == cap) {  // :838-840 then the trailing end-of-block peek :1009-1015
             if (left >= 15 && ((uint32_t)bb & eof_mask) == eof_code) {
@@ -497,7 +498,6 @@ struct Inflater {
             if (left < nb) return RC_STUCK;
             put_byte((e >> 8) & 0xFF);
             consume(nb);
-            if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
             return RC_OK;
         }
         if (kind == K_LIT2) {
@@ -506,7 +506,6 @@ struct Inflater {
             consume(nb);
             if (opos == cap) return RC_STUCK;  // second literal queued, :866-876
             put_byte((e >> 16) & 0xFF);
-            if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
             return RC_OK;
         }
         uint32_t len_base, len_extra, lcb;
@@ -517,7 +516,6 @@ struct Inflater {
             if (sym < 256) {
                 consume(lcb);
                 put_byte(sym);
-                if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack)) flush(false);
                 return RC_OK;
             }
             if (sym == 256) {
@@ -598,14 +596,15 @@ struct Inflater {
         int64_t la64 = (int64_t)left - (int64_t)kTileBits * lane;
         const int32_t la = la64 > (1 << 20) ? (1 << 20) : (la64 < -1 ? -1 : (int32_t)la64);
 
-        auto bits32 = [&](uint32_t p) -> uint32_t {  // 32 stream bits starting at chunk bit p (< 96)
-            uint32_t lo = p < 32 ? w0 : (p < 64 ? w1 : w2);
-            uint32_t hi = p < 32 ? w1 : (p < 64 ? w2 : w3);
+        auto bits32 = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t {  // 32 stream bits starting at chunk bit p (< 96)
+            const bool a = p < 32, b = p < 64;
+            uint32_t lo = vsel(a, w0, vsel(b, w1, w2));
+            uint32_t hi = vsel(a, w1, vsel(b, w2, w3));
             return __builtin_amdgcn_alignbit(hi, lo, p & 31);
         };
         // Decodes the token at chunk bit p.  kind: 0 literal(s), 1 match, 2 end-of-block, 3 bad.
         // adv1: bits of the first symbol; adv: bits of the whole table entry / token.
-        auto token = [&](uint32_t p, uint32_t& kind, uint32_t& adv1, uint32_t& adv) {
+        auto token = [&](uint32_t p, uint32_t& kind, uint32_t& adv1, uint32_t& adv) __attribute__((always_inline)) {
             uint32_t e = T.lit[bits32(p) & (kLitSize - 1)];
             uint32_t nb = e & 15, k = (e >> 4) & 15;
             if (k <= K_LIT2) {
@@ -856,25 +855,29 @@ struct Inflater {
         }
     }
 
-    // ------------------------------------------------------------------ checksum
-    __device__ __forceinline__ uint32_t finish_checksum() {  // src/decompress.rs:306-326
+    // ------------------------------------------------------------------ checksum / results
+    // src/decompress.rs:306-326: skip to the byte boundary, read the big-endian Adler-32.
+    __device__ __forceinline__ uint32_t read_trailer(uint32_t& stored) {
         refill();
         uint32_t align = (uint32_t)(left & 7);
         if (left < 32 + align) return RC_STUCK;
         consume(align);
         refill();
-        uint32_t stored = __builtin_bswap32((uint32_t)bb);
+        stored = __builtin_bswap32((uint32_t)bb);
         consume(32);
-        flush(true);
-        uint32_t adler = (adler_b << 16) | adler_a;
-        if (!(flags & 1u) && stored != adler) return ST_WRONG_CHECKSUM;
         return RC_OK;
     }
 
-    __device__ __forceinline__ StreamResult finish(uint32_t rc) {
+    // Final flush (the only one that may store a partial line) + classification.
+    // rc = RC_OK means "trailer read": the checksum comparison happens here, after the flush.
+    __device__ __forceinline__ StreamResult finish(uint32_t rc, uint32_t stored) {
         StreamResult r;
         r.ambiguous = false;
-        if (rc == RC_STUCK) {
+        flush(true);
+        uint32_t adler = (adler_b << 16) | adler_a;
+        if (rc == RC_OK) {
+            r.status = (!(flags & 1u) && stored != adler) ? (uint32_t)ST_WRONG_CHECKSUM : (uint32_t)ST_OK;
+        } else if (rc == RC_STUCK) {
             // src/decompress.rs:1126-1139: not done and no error -> OutputTooLarge if the slot is
             // full, InsufficientInput otherwise.
             r.status = (opos == cap) ? ST_OUTPUT_TOO_LARGE : ST_INSUFFICIENT_INPUT;
@@ -882,9 +885,8 @@ struct Inflater {
         } else {
             r.status = rc;
         }
-        flush(true);
         r.out_len = opos;
-        r.adler = (adler_b << 16) | adler_a;
+        r.adler = adler;
         return r;
     }
 
@@ -892,22 +894,23 @@ struct Inflater {
     // recognised by the caller and the tables are in place.
     template <bool TILES, bool START_IN_BLOCK>
     __device__ __forceinline__ StreamResult run() {
-        uint32_t rc;
-        if (!START_IN_BLOCK) {
-            rc = parse_zlib_header();
-            if (rc != RC_OK) return finish(rc);
-        }
-        for (;;) {
+        uint32_t rc = RC_OK, stored = 0;
+        if (!START_IN_BLOCK) rc = parse_zlib_header();
+        while (rc == RC_OK) {
             if (!START_IN_BLOCK) {
                 rc = parse_block_header();
                 if (rc == RC_OK) rc = decode_block_data<TILES>();
             } else {
                 rc = decode_block_data<TILES>();
             }
-            if (rc != RC_EOB) return finish(rc);
-            if (last_block) break;
+            if (rc != RC_EOB) break;  // stuck or error
+            if (last_block) {
+                rc = read_trailer(stored);
+                break;
+            }
+            rc = RC_OK;
         }
-        return finish(finish_checksum());
+        return finish(rc, stored);
     }
 };
 

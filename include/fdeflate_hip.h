@@ -65,6 +65,8 @@ enum {
 #define FDH_FLAG_SERIAL_ONLY    0x2u /* debug/A-B: force the per-symbol wave-serial decoder */
 #define FDH_FLAG_GENERAL_ONLY   0x4u /* debug/A-B: skip the shared-table kernel */
 #define FDH_FLAG_NO_RECHECK     0x8u /* tests: do not re-derive non-Ok results serially */
+#define FDH_FLAG_FORCE_LANES    0x10u /* tests/A-B: stream-per-lane kernel even for small batches */
+#define FDH_FLAG_NO_LANES       0x20u /* tests/A-B: never use the stream-per-lane kernel */
 
 /*
  * fdh_inflate_batch -- one-shot decode of `n` independent zlib streams, one wavefront each.

@@ -138,7 +138,7 @@ def test_valid_streams_every_decoder_variant(harness):
             names.append("%s@%d" % (name, c))
             blobs.append(comp)
             caps.append(c)
-    for flags in (8, 4 | 8, 2):
+    for flags in (8, 4 | 8, 2, 16, 16 | 8):
         harness.assert_inflate_parity(names, blobs, caps, flags=flags)
 
 
@@ -177,6 +177,7 @@ def test_error_streams(harness):
     blobs = [b for _, b, _ in items]
     for cap in (1 << 16, 4, 0):
         harness.assert_inflate_parity(names, blobs, [cap] * len(items))
+    harness.assert_inflate_parity(names, blobs, [1 << 16] * len(items), flags=16)  # via the lane kernel
     st, _, _, _, _ = harness.gpu_inflate(blobs, [1 << 16] * len(items))
     for (name, _, expect), s in zip(items, st):
         assert ob.STATUS_NAMES[int(s)] == expect, (name, ob.STATUS_NAMES[int(s)], expect)
@@ -188,6 +189,7 @@ def test_mutation_fuzz_parity(harness):
     blobs = [b for _, b in items]
     for cap in (1 << 16, 1000):
         harness.assert_inflate_parity(names, blobs, [cap] * len(items))
+        harness.assert_inflate_parity(names, blobs, [cap] * len(items), flags=16)
 
 
 def test_truncation_sweep(harness):
@@ -204,6 +206,7 @@ def test_truncation_sweep(harness):
             blobs.append(base[:cut])
     for cap in (1 << 12, 100, 24):
         harness.assert_inflate_parity(names, blobs, [cap] * len(blobs))
+        harness.assert_inflate_parity(names, blobs, [cap] * len(blobs), flags=16)
 
 
 def test_ultrafast_encode_bit_exact(harness):

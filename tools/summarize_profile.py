@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile.sh run into small files under gpurun_out/prof_<tag>/summary/ (copy
+them into profiles/): kernel stats of our kernels, per-kernel PMC averages, and the HBM traffic
+per launch with the gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B
+request for wide streaming reads -> doubled; both counters are in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+sumdir = os.path.join(out, "summary")
+os.makedirs(sumdir, exist_ok=True)
+OURS = ("fdh::",)
+
+
+def ours(name):
+    return any(k in name for k in OURS)
+
+
+# kernel stats
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if ours(r["Name"])]
+    with open(os.path.join(sumdir, "%s_kernel_stats.csv" % tag), "w") as g:
+        w = csv.writer(g)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]])
+    for r in rows:
+        print("stats", r["Name"][:60], "calls", r["Calls"], "avg_ms", float(r["AverageNs"]) / 1e6)
+
+# pmc
+pmc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "")
+        if ours(name):
+            pmc[name.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, cs in pmc.items():
+    res[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+    res[k]["_launches"] = {c: len(v) for c, v in cs.items()}
+traffic = {}
+for k, cs in res.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        fetch_b = cs["FETCH_SIZE"] * 1024 * 2   # gfx950: wide streaming reads are under-counted 2x
+        write_b = cs["WRITE_SIZE"] * 1024
+        traffic[k] = {"fetch_bytes_corrected": fetch_b, "fetch_bytes_raw": cs["FETCH_SIZE"] * 1024,
+                      "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b}
+json.dump({"pmc_avg_per_launch": res, "traffic": traffic}, open(os.path.join(sumdir, "%s_pmc.json" % tag), "w"), indent=1)
+for k, cs in res.items():
+    print("pmc", k)
+    for c, v in sorted(cs.items()):
+        if not c.startswith("_"):
+            print("    %-24s %.4g" % (c, v))
+for k, t in traffic.items():
+    print("traffic", k, {a: "%.4g" % b for a, b in t.items()})
