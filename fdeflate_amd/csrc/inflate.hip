@@ -19,6 +19,7 @@
 // by the symbol-serial decoder, whose pairing is the reference's (DESIGN.md "error parity").
 #include "inflate_stream.h"
 #include "inflate_lanes.h"
+#include "inflate_segments.h"
 
 namespace fdh {
 
@@ -135,6 +136,11 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
     __shared__ CanonLds lds;
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x / kWave;
+    const uint64_t sid = (uint64_t)blockIdx.x * kCanonWaves + wid;
+    // when this kernel only mops up after the segment kernel, most workgroups have nothing to do:
+    // find that out before staging 18 KiB of tables
+    const bool mine = sid < a.n && (!a.only_pending || a.status[sid] == kPending);
+    if (!__syncthreads_or(mine ? 1 : 0)) return;
     // stage the shared tables: 16 B per lane, coalesced, served from L2 after the first workgroups
     {
         const uint4* src = reinterpret_cast<const uint4*>(g_canon.lit);
@@ -146,9 +152,7 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
         if (threadIdx.x < 4) lds.tables.eof[threadIdx.x] = g_canon.eof[threadIdx.x];
     }
     __syncthreads();
-    const uint64_t sid = (uint64_t)blockIdx.x * kCanonWaves + wid;
-    if (sid >= a.n) return;
-    if (a.only_pending && a.status[sid] != kPending) return;  // the lane kernel already finished it
+    if (!mine) return;
     const StreamArgs s = stream_args(a, sid);
     Inflater inf(lds.tables, lds.io[wid], nullptr, lane);
     inf.init(s);
@@ -199,6 +203,19 @@ __global__ __launch_bounds__(kLaneBlock) void inflate_lanes_kernel(LaneArgs a) {
     }
     __syncthreads();
     lanes_decode(a, lds);
+}
+
+// Canonical streams, segment-parallel: one stream per wavefront, one segment per lane
+// (inflate_segments.h).
+__global__ __launch_bounds__(kSegWaves* kWave) void inflate_segments_kernel(SegArgs a) {
+    __shared__ SegLds lds;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit);
+        uint4* dst = reinterpret_cast<uint4*>(lds.lit);
+        for (int i = threadIdx.x; i < kLitSize / 4; i += kSegWaves * kWave) dst[i] = src[i];
+    }
+    __syncthreads();
+    segments_decode(a, lds);
 }
 
 // Parses the canonical prefix once per device and keeps the resulting tables in g_canon.
@@ -266,6 +283,11 @@ __global__ __launch_bounds__(kWave) void build_tables_debug_kernel(const uint8_t
 }  // namespace fdh
 
 #ifdef FDH_DEBUG_TILES
+extern "C" int fdh_debug_read_seg(uint32_t* host) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segdbg), 64 * 16 * 4);
+    return 0;
+}
 extern "C" int fdh_debug_read(uint32_t* host, uint32_t nwords, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(host + 8, HIP_SYMBOL(fdh::g_dbg), (nwords - 8) * 4, 32);
@@ -305,10 +327,27 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         return (int)hipGetLastError();
     }
     hipError_t e;
+    // Canonical streams of useful length: segment-parallel kernel first; what it cannot finish
+    // stays PENDING for the kernels below.
+    if (!(flags & 128u)) {
+        int ordinal = 0;
+        e = hipGetDevice(&ordinal);
+        if (e != hipSuccess) return (int)e;
+        fdh::CanonTables* canon = (ordinal >= 0 && ordinal < 64) ? g_canon_dev[ordinal] : nullptr;
+        if (!canon) return (int)hipErrorNotInitialized;
+        fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->hdr,
+                        fdh::kCanonBits, fdh::kPending};
+        unsigned sblocks = (unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves);
+        hipLaunchKernelGGL(fdh::inflate_segments_kernel, dim3(sblocks), dim3(fdh::kSegWaves * fdh::kWave), 0, stream, sa);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        a.only_pending = 1;
+        if (flags & 64u) return 0;  // debug: first kernel only (PENDING streams stay undecoded)
+    }
     // Dense batches first go through the stream-per-lane kernel; it finishes the canonical
     // streams that decode cleanly and leaves everything else PENDING.
     const bool lanes = (flags & 16u) || (n >= fdh::kLaneMinStreams && !(flags & 32u));
-    if (lanes) {
+    if (lanes && a.only_pending == 0) {
         int ordinal = 0;
         e = hipGetDevice(&ordinal);
         if (e != hipSuccess) return (int)e;

@@ -202,7 +202,7 @@ __device__ __forceinline__ void lanes_decode(const LaneArgs& a, LaneLds& L) {
         const uint32_t dbit = (win >> (nb + ex)) & 1;
         uint32_t used = nb + (is_len ? ex + 1 : 0);
         uint32_t n = is_lit ? kind + 1 : 0;
-        uint64_t v = (e >> 8) & (kind == K_LIT2 ? 0xFFFFu : 0xFFu);
+        uint64_t v = is_lit ? ((e >> 8) & (kind == K_LIT2 ? 0xFFFFu : 0xFFu)) : 0u;  // bytes only for literals
         bool bad = !(is_lit || is_len || is_eob) || (is_len && (dbit != 0 || opos + acc_n == 0));
         uint32_t new_fill = is_len ? length : 0;
         uint32_t new_last = kind == K_LIT2 ? (e >> 16) & 0xFF : (e >> 8) & 0xFF;

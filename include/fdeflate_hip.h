@@ -67,6 +67,8 @@ enum {
 #define FDH_FLAG_NO_RECHECK     0x8u /* tests: do not re-derive non-Ok results serially */
 #define FDH_FLAG_FORCE_LANES    0x10u /* tests/A-B: stream-per-lane kernel even for small batches */
 #define FDH_FLAG_NO_LANES       0x20u /* tests/A-B: never use the stream-per-lane kernel */
+#define FDH_FLAG_FIRST_ONLY     0x40u /* debug: run only the first kernel of the pipeline */
+#define FDH_FLAG_NO_SEGMENTS    0x80u /* tests/A-B: skip the segment-parallel kernel */
 
 /*
  * fdh_inflate_batch -- one-shot decode of `n` independent zlib streams, one wavefront each.

@@ -138,8 +138,55 @@ def test_valid_streams_every_decoder_variant(harness):
             names.append("%s@%d" % (name, c))
             blobs.append(comp)
             caps.append(c)
-    for flags in (8, 4 | 8, 2, 16, 16 | 8):
+    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8):
         harness.assert_inflate_parity(names, blobs, caps, flags=flags)
+
+
+def test_segment_kernel_long_canonical_streams(harness):
+    """Long ultra-fast streams take the segment-parallel kernel (>= ~8 KiB compressed).  Every
+    content class, odd lengths, exact / loose / short slots, plus corrupted and truncated copies
+    that must fall through to the exact kernels with the reference's status."""
+    from fdeflate_amd import synth
+    r = np.random.default_rng(77)
+    raws = []
+    for i in (0, 1, 7, 15, 16, 23, 40):
+        raws.append(synth.gen_stream_np(i, 65536).tobytes())
+    raws.append(synth.gen_stream_np(2, 65536, "M").tobytes())
+    raws.append(synth.gen_stream_np(3, 65536, "L").tobytes())
+    raws.append(synth.gen_stream_np(4, 65536, "U").tobytes())
+    raws.append(r.integers(0, 256, 30011, dtype=np.uint8).tobytes())
+    raws.append((r.integers(0, 256, 70001, dtype=np.uint8) % 3).astype(np.uint8).tobytes())
+    for n in (20000, 65536, 131072 + 5):
+        x = r.integers(0, 256, n, dtype=np.uint8)
+        x[r.random(n) < 0.6] = 0
+        raws.append(x.tobytes())
+        y = r.integers(1, 256, n, dtype=np.uint8)   # no zeros at all: literals only
+        raws.append(y.tobytes())
+        z = x.copy()
+        z[n // 3: n // 3 + 5000] = 0                # one long run in the middle
+        raws.append(z.tobytes())
+    names, blobs, caps = [], [], []
+    for k, raw in enumerate(raws):
+        comp = ob.compress_ultra_fast(raw)
+        for c in (len(raw), len(raw) + 33, len(raw) - 1, len(raw) // 2):
+            names.append("seg%d@%d" % (k, c))
+            blobs.append(comp)
+            caps.append(c)
+        bad = bytearray(comp)
+        bad[len(bad) // 2] ^= 0x10
+        names.append("seg%d_flip" % k)
+        blobs.append(bytes(bad))
+        caps.append(len(raw) + 100)
+        bad = bytearray(comp)
+        bad[-2] ^= 0x01
+        names.append("seg%d_adler" % k)
+        blobs.append(bytes(bad))
+        caps.append(len(raw))
+        names.append("seg%d_trunc" % k)
+        blobs.append(comp[:len(comp) * 2 // 3])
+        caps.append(len(raw))
+    harness.assert_inflate_parity(names, blobs, caps)
+    harness.assert_inflate_parity(names, blobs, caps, flags=128)
 
 
 def test_valid_streams_ignore_adler(harness):
