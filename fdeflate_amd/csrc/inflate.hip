@@ -64,6 +64,7 @@ struct InflateBatchArgs {
     uint64_t n;
     uint32_t flags;
     uint32_t only_pending;
+    const uint32_t* list;  // nullable: compacted ids of the PENDING streams ([0] = count, [4..] = ids)
 };
 
 __device__ __forceinline__ StreamArgs stream_args(const InflateBatchArgs& a, uint64_t sid) {
@@ -136,10 +137,17 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
     __shared__ CanonLds lds;
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x / kWave;
-    const uint64_t sid = (uint64_t)blockIdx.x * kCanonWaves + wid;
+    uint64_t sid = (uint64_t)blockIdx.x * kCanonWaves + wid;
     // when this kernel only mops up after the segment kernel, most workgroups have nothing to do:
-    // find that out before staging 18 KiB of tables
-    const bool mine = sid < a.n && (!a.only_pending || a.status[sid] == kPending);
+    // find that out before staging 18 KiB of tables.  With a compacted list the leftovers are
+    // packed 8 to a workgroup.
+    bool mine;
+    if (a.list) {
+        mine = sid < a.list[0];
+        if (mine) sid = a.list[4 + sid];
+    } else {
+        mine = sid < a.n && (!a.only_pending || a.status[sid] == kPending);
+    }
     if (!__syncthreads_or(mine ? 1 : 0)) return;
     // stage the shared tables: 16 B per lane, coalesced, served from L2 after the first workgroups
     {
@@ -321,7 +329,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0};
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr};
     if (flags & 6u) {  // FDH_FLAG_SERIAL_ONLY (2) / debug: general kernel only, tiles allowed (4)
         hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
         return (int)hipGetLastError();
@@ -335,14 +343,37 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         if (e != hipSuccess) return (int)e;
         fdh::CanonTables* canon = (ordinal >= 0 && ordinal < 64) ? g_canon_dev[ordinal] : nullptr;
         if (!canon) return (int)hipErrorNotInitialized;
+        // stream-ordered scratch for the compacted list of leftovers (no host synchronisation)
+        uint32_t* list = nullptr;
+        if (hipMallocAsync(reinterpret_cast<void**>(&list), (n + 4) * sizeof(uint32_t), stream) != hipSuccess) {
+            (void)hipGetLastError();
+            list = nullptr;  // fall back to the status-scan form
+        } else {
+            e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
+            if (e != hipSuccess) return (int)e;
+        }
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->hdr,
-                        fdh::kCanonBits, fdh::kPending};
+                        fdh::kCanonBits, fdh::kPending, list};
         unsigned sblocks = (unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves);
         hipLaunchKernelGGL(fdh::inflate_segments_kernel, dim3(sblocks), dim3(fdh::kSegWaves * fdh::kWave), 0, stream, sa);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         a.only_pending = 1;
-        if (flags & 64u) return 0;  // debug: first kernel only (PENDING streams stay undecoded)
+        if (flags & 64u) {  // debug: first kernel only (PENDING streams stay undecoded)
+            if (list) (void)hipFreeAsync(list, stream);
+            return 0;
+        }
+        if (list) {
+            a.list = list;
+            unsigned cblocks = (unsigned)((n + fdh::kCanonWaves - 1) / fdh::kCanonWaves);
+            hipLaunchKernelGGL(fdh::inflate_canon_kernel, dim3(cblocks), dim3(fdh::kCanonWaves * fdh::kWave), 0, stream, a);
+            e = hipGetLastError();
+            a.list = nullptr;
+            (void)hipFreeAsync(list, stream);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
+            return (int)hipGetLastError();
+        }
     }
     // Dense batches first go through the stream-per-lane kernel; it finishes the canonical
     // streams that decode cleanly and leaves everything else PENDING.

@@ -71,7 +71,17 @@ struct SegArgs {
     const uint32_t* canon_hdr;  // 14 dwords of prefix (last one masked)
     uint32_t canon_bits;
     uint32_t pending;
+    uint32_t* list;  // nullable: [0] = count, [4..] = ids of the streams left PENDING (compacted)
 };
+
+// Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).
+__device__ __forceinline__ void seg_leave_pending(const SegArgs& a, uint64_t sid) {
+    a.status[sid] = a.pending;
+    if (a.list) {
+        uint32_t k = atomicAdd(&a.list[0], 1u);
+        a.list[4 + k] = (uint32_t)sid;
+    }
+}
 
 // 16 bytes from a 16-B aligned address, zero where outside [lo, hi).
 __device__ __attribute__((noinline)) uint4 seg_load16_edge(const uint8_t* p, const uint8_t* lo, const uint8_t* hi) {
@@ -283,7 +293,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         ours = !__any(mismatch);
     }
     if (!ours) {
-        if (lane == 0) a.status[sid] = a.pending;
+        if (lane == 0) seg_leave_pending(a, sid);
         return;
     }
     // ---- segments: 64 equal bit ranges of the block data (the trailer bits ride along) ----
@@ -416,7 +426,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     SEGDBG(8, (uint32_t)stop_lane | ((uint32_t)first_unver << 8) | (stop_kind << 16) | ((giveup ? 1u : 0u) << 24));
     SEGDBG(9, total);
     if (!ok) {
-        if (lane == 0) a.status[sid] = a.pending;
+        if (lane == 0) seg_leave_pending(a, sid);
         return;
     }
 
@@ -535,7 +545,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     SEGDBG(12, (uint32_t)__ballot(wrong_count));
     SEGDBG(13, (uint32_t)(__ballot(wrong_count) >> 32));
     if (__any(bad2 || wrong_count)) {
-        if (lane == 0) a.status[sid] = a.pending;
+        if (lane == 0) seg_leave_pending(a, sid);
         return;
     }
     // ---- combine the Adler-32 partials: A = 1 + sum a_i ; B = total + sum (b_i + rest_i * a_i) ----
@@ -558,7 +568,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             a.out_len[sid] = total;
             if (a.adler) a.adler[sid] = adler;
         } else {
-            a.status[sid] = a.pending;  // the exact kernels report WrongChecksum
+            seg_leave_pending(a, sid);  // the exact kernels report WrongChecksum
         }
     }
 }
