@@ -20,7 +20,10 @@ def gather_metadata(status, out_len, adler, group=None):
     meta = torch.stack([status.to(torch.int32), out_len.to(torch.int32), adler.to(torch.int32)])
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(meta.shape), dtype=meta.dtype, device=meta.device)
-    dist.all_gather_into_tensor(out, meta.contiguous(), group=group)
+    if dist.get_backend(group) == "nccl":  # RCCL: one flat all-gather over xGMI
+        dist.all_gather_into_tensor(out, meta.contiguous(), group=group)
+    else:  # gloo (CPU tests)
+        dist.all_gather(list(out.unbind(0)), meta.contiguous(), group=group)
     return out
 
 
@@ -28,5 +31,8 @@ def gather_payload(out, group=None):
     """Optional payload gather (link-bound over xGMI: timed separately by the bench)."""
     world = dist.get_world_size(group)
     full = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=out.device)
-    dist.all_gather_into_tensor(full, out.contiguous(), group=group)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(full, out.contiguous(), group=group)
+    else:
+        dist.all_gather(list(full.unbind(0)), out.contiguous(), group=group)
     return full

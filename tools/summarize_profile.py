@@ -50,6 +50,17 @@ for k, cs in res.items():
         traffic[k] = {"fetch_bytes_corrected": fetch_b, "fetch_bytes_raw": cs["FETCH_SIZE"] * 1024,
                       "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b}
 json.dump({"pmc_avg_per_launch": res, "traffic": traffic}, open(os.path.join(sumdir, "%s_pmc.json" % tag), "w"), indent=1)
+# per-step HBM traffic of the decode / encode paths (all kernels of the path added up)
+step = {}
+dec = sum(t["hbm_bytes_per_launch"] for k, t in traffic.items() if "inflate" in k)
+enc = sum(t["hbm_bytes_per_launch"] for k, t in traffic.items() if "deflate" in k)
+if dec:
+    step["decode"] = {"hbm_bytes_per_step": dec, "kernels": [k for k in traffic if "inflate" in k],
+                      "note": "FETCH_SIZE*1024*2 (gfx950 under-count of wide reads) + WRITE_SIZE*1024, separate --pmc passes"}
+if enc:
+    step["encode"] = {"hbm_bytes_per_step": enc, "kernels": [k for k in traffic if "deflate" in k],
+                      "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes"}
+json.dump(step, open(os.path.join(sumdir, "traffic_latest.json"), "w"), indent=1)
 for k, cs in res.items():
     print("pmc", k)
     for c, v in sorted(cs.items()):
