@@ -40,7 +40,7 @@ __device__ uint32_t g_segdbg[64 * 16];
 #define SEGDBG_ADD(slot, val) do { } while (0)
 #endif
 
-constexpr int kSegWaves = 4;        // wavefronts (= streams) per workgroup
+constexpr int kSegWaves = 8;        // wavefronts (= streams) per workgroup: 80 KiB LDS -> 16 wavefronts/CU
 constexpr int kSegInWords = 16;     // per-lane input ring: 16 dwords (64 B)
 constexpr int kSegOutWords = 8;     // per-lane output ring: 8 qwords (64 B)
 constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation
@@ -55,6 +55,9 @@ struct SegWaveLds {
 struct SegLds {
     uint32_t lit[kLitSize];
     SegWaveLds w[kSegWaves];
+#ifdef FDH_SEG_PAD_LDS
+    uint32_t pad[FDH_SEG_PAD_LDS / 4];
+#endif
 };
 
 struct SegArgs {
@@ -217,46 +220,50 @@ __device__ __forceinline__ uint32_t seg_scan(const uint32_t* lit, SegReader& rd,
     if (active) rd.start(in, seg_bit0 + s.pos);
     uint32_t iter = 0;
     bool running = active && s.pos < stop_at;
+    // Outer loop = one global-memory event, inner loop = 8 table look-ups that touch neither the
+    // in-flight load registers nor global memory (so the compiler keeps waits and copies out of it).
     while (__any(running)) {
-        if (EVENTS) {
-            if ((iter & 7) == 0) rd.event(running);
+        if (EVENTS) rd.event(running);
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            iter++;
+            // straight-line step: every lane looks up; only `running` lanes commit (selects only)
+            SegToken t = seg_token(lit, rd.window());
+            // Close to the window's end a literal pair is taken one literal at a time: the guessed
+            // and the real chain may pair literals differently, but they then still cross the
+            // window on the same symbol boundary.
+            const bool single = t.is_lit && t.n == 2 && s.pos + 24 >= (uint32_t)kSegWindow && s.pos < (uint32_t)kSegWindow;
+            t.used = single ? t.used1 : t.used;
+            t.n = single ? 1u : t.n;
+            t.lastlit = single ? (t.v & 0xFF) : t.lastlit;
+            bool fault = t.bad || (seg_bit0 + s.pos + t.used > in_bits) || rd.starved();
+            if (RECORD_CROSS) {
+                // Inside the window the guessed chain is only a way to find a synchronisation
+                // point: an impossible token (or a stray end-of-block) there just means "not
+                // synchronised yet", so slide on by one bit.  The landing check is what
+                // guarantees correctness.
+                const bool slide = s.pos < (uint32_t)kSegWindow && (t.bad || t.is_eob) && !rd.starved() &&
+                                   seg_bit0 + s.pos + 1 <= in_bits;
+                t.used = slide ? 1u : t.used;
+                t.n = slide ? 0u : t.n;
+                t.run = slide ? 0u : t.run;
+                t.is_lit = slide ? false : t.is_lit;
+                t.is_eob = slide ? false : t.is_eob;
+                fault = slide ? false : fault;
+            }
+            const bool step = running && !fault && !t.is_eob;
+            const bool halt = running && !step;
+            s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+            s.eob_bits = halt ? t.used : s.eob_bits;
+            const bool counted = step && s.pos >= count_from;
+            s.count += counted ? t.n + t.run : 0u;
+            s.lastlit = (counted && t.is_lit) ? t.lastlit : s.lastlit;
+            const uint32_t used = step ? t.used : 0u;
+            s.pos += used;
+            rd.consume_sel(used);
+            if (RECORD_CROSS) s.cross = (s.cross == 0 && s.pos >= (uint32_t)kSegWindow) ? s.pos : s.cross;
+            running = step && s.pos < stop_at;
         }
-        iter++;
-        // straight-line step: every lane looks up; only `running` lanes commit (selects, no branches)
-        SegToken t = seg_token(lit, rd.window());
-        // Close to the window's end a literal pair is taken one literal at a time: the guessed and
-        // the real chain may pair literals differently, but they then still cross the window on
-        // the same symbol boundary.
-        const bool single = t.is_lit && t.n == 2 && s.pos + 24 >= (uint32_t)kSegWindow && s.pos < (uint32_t)kSegWindow;
-        t.used = single ? t.used1 : t.used;
-        t.n = single ? 1u : t.n;
-        t.lastlit = single ? (t.v & 0xFF) : t.lastlit;
-        bool fault = t.bad || (seg_bit0 + s.pos + t.used > in_bits) || rd.starved();
-        if (RECORD_CROSS) {
-            // Inside the window the guessed chain is only a way to find a synchronisation point:
-            // an impossible token (or a stray end-of-block) there just means "not synchronised
-            // yet", so slide on by one bit.  The landing check is what guarantees correctness.
-            const bool slide = s.pos < (uint32_t)kSegWindow && (t.bad || t.is_eob) && !rd.starved() &&
-                               seg_bit0 + s.pos + 1 <= in_bits;
-            t.used = slide ? 1u : t.used;
-            t.n = slide ? 0u : t.n;
-            t.run = slide ? 0u : t.run;
-            t.is_lit = slide ? false : t.is_lit;
-            t.is_eob = slide ? false : t.is_eob;
-            fault = slide ? false : fault;
-        }
-        const bool step = running && !fault && !t.is_eob;
-        const bool halt = running && !step;
-        s.stop = halt ? (fault ? 2u : 1u) : s.stop;
-        s.eob_bits = halt ? t.used : s.eob_bits;
-        const bool counted = step && s.pos >= count_from;
-        s.count += counted ? t.n + t.run : 0u;
-        s.lastlit = (counted && t.is_lit) ? t.lastlit : s.lastlit;
-        const uint32_t used = step ? t.used : 0u;
-        s.pos += used;
-        rd.consume_sel(used);
-        if (RECORD_CROSS) s.cross = (s.cross == 0 && s.pos >= (uint32_t)kSegWindow) ? s.pos : s.cross;
-        running = step && s.pos < stop_at;
     }
     return iter;
 }
@@ -485,38 +492,40 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     if (live) rd.start(in, seg_bit0 + pos);
     bool running = live && (pos < my_end || fill);
     uint32_t iter = 0;
+    // Outer loop = drain + (every other time) input event; inner loop = 4 straight-line steps.
     while (__any(running)) {
-        if ((iter & 3) == 0) {
-            drain();
-            if ((iter & 7) == 0) rd.event(running);
+        drain();
+        if ((iter & 4) == 0) rd.event(running);
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            iter++;
+            // straight-line step (selects only): a table look-up or 8 bytes of a run
+            const SegToken t = seg_token(lit, rd.window());
+            const bool filling = fill != 0;
+            const bool dec = running && !filling;  // this lane decodes a token now
+            bad2 = bad2 || (dec && (t.bad || t.is_eob || rd.starved() || (t.is_run && last == kNoByte)));
+            const uint32_t nfill = min(fill, 8u);
+            uint64_t vfill = (uint64_t)(last & 0xFF) * 0x0101010101010101ull;
+            vfill = nfill < 8 ? (vfill & ((1ull << (8 * nfill)) - 1)) : vfill;
+            const uint32_t n = running ? (filling ? nfill : t.n) : 0u;
+            const uint64_t v = running ? (filling ? vfill : (uint64_t)t.v) : 0ull;
+            fill = running ? (filling ? fill - nfill : t.run) : fill;
+            last = (dec && t.is_lit) ? t.lastlit : last;
+            const uint32_t used = dec ? t.used : 0u;
+            pos += used;
+            rd.consume_sel(used);
+            // append n bytes; the ring slot at vpos is always free, so the (possibly partial)
+            // accumulator is written there unconditionally and only counts once it is full
+            const uint32_t tot = acc_n + n;
+            acc |= v << (8 * acc_n);
+            const bool full = tot >= 8;
+            my_out[((vpos >> 3) & (kSegOutWords - 1)) * kWave] = acc;
+            vpos += full ? 8u : 0u;
+            const uint64_t spill = acc_n ? (v >> (8 * (8 - acc_n))) : 0ull;
+            acc = full ? spill : acc;
+            acc_n = full ? tot - 8 : tot;
+            running = running && !bad2 && (pos < my_end || fill != 0);
         }
-        iter++;
-        // straight-line step (selects only): a table look-up or 8 bytes of a run
-        const SegToken t = seg_token(lit, rd.window());
-        const bool filling = fill != 0;
-        const bool dec = running && !filling;  // this lane decodes a token now
-        bad2 = bad2 || (dec && (t.bad || t.is_eob || rd.starved() || (t.is_run && last == kNoByte)));
-        const uint32_t nfill = min(fill, 8u);
-        uint64_t vfill = (uint64_t)(last & 0xFF) * 0x0101010101010101ull;
-        vfill = nfill < 8 ? (vfill & ((1ull << (8 * nfill)) - 1)) : vfill;
-        const uint32_t n = running ? (filling ? nfill : t.n) : 0u;
-        const uint64_t v = running ? (filling ? vfill : (uint64_t)t.v) : 0ull;
-        fill = running ? (filling ? fill - nfill : t.run) : fill;
-        last = (dec && t.is_lit) ? t.lastlit : last;
-        const uint32_t used = dec ? t.used : 0u;
-        pos += used;
-        rd.consume_sel(used);
-        // append n bytes; the ring slot at vpos is always free, so the (possibly partial)
-        // accumulator is written there unconditionally and only counts once it is full
-        const uint32_t tot = acc_n + n;
-        acc |= v << (8 * acc_n);
-        const bool full = tot >= 8;
-        my_out[((vpos >> 3) & (kSegOutWords - 1)) * kWave] = acc;
-        vpos += full ? 8u : 0u;
-        const uint64_t spill = acc_n ? (v >> (8 * (8 - acc_n))) : 0ull;
-        acc = full ? spill : acc;
-        acc_n = full ? tot - 8 : tot;
-        running = running && !bad2 && (pos < my_end || fill != 0);
     }
     SEGDBG(4, iter);
     SEGDBG(7, total);
