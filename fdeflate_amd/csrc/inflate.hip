@@ -217,10 +217,13 @@ __global__ __launch_bounds__(kLaneBlock) void inflate_lanes_kernel(LaneArgs a) {
 // (inflate_segments.h).
 __global__ __launch_bounds__(kSegWaves* kWave) void inflate_segments_kernel(SegArgs a) {
     __shared__ SegLds lds;
-    {
+    {  // stage the canonical table, converted to this kernel's entry layout
         const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit);
         uint4* dst = reinterpret_cast<uint4*>(lds.lit);
-        for (int i = threadIdx.x; i < kLitSize / 4; i += kSegWaves * kWave) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kLitSize / 4; i += kSegWaves * kWave) {
+            const uint4 e = src[i];
+            dst[i] = make_uint4(seg_entry_from(e.x), seg_entry_from(e.y), seg_entry_from(e.z), seg_entry_from(e.w));
+        }
     }
     __syncthreads();
     segments_decode(a, lds);

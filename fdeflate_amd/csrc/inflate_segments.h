@@ -18,7 +18,7 @@
 //   scan    a wavefront prefix sum of the byte counts gives every lane its output offset;
 //           the byte a leading run repeats comes from the nearest lane to the left that emitted
 //           a literal.
-//   pass 2  every lane decodes its real chain again and streams the bytes through an 8-byte
+//   pass 2  every lane decodes its real chain again and streams the bytes through a 4-byte
 //           accumulator and a small LDS ring to 16-B aligned global stores, folding them into a
 //           per-lane Adler-32 partial; the partials are combined with the block-combine identity.
 //
@@ -42,15 +42,44 @@ __device__ uint32_t g_segdbg[64 * 16];
 
 constexpr int kSegWaves = 8;        // wavefronts (= streams) per workgroup: 80 KiB LDS -> 16 wavefronts/CU
 constexpr int kSegInWords = 16;     // per-lane input ring: 16 dwords (64 B)
-constexpr int kSegOutWords = 8;     // per-lane output ring: 8 qwords (64 B)
+constexpr int kSegOutWords = 16;    // per-lane output ring: 16 dwords (64 B)
 constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation
+constexpr int kSegSteps = 8;        // table look-ups between two global-memory events
 constexpr uint32_t kSegMinBits = 4 * kSegWindow;  // shorter segments: not worth it -> PENDING
+#ifndef FDH_BULK
+#define FDH_BULK 64
+#endif
+constexpr uint32_t kSegBulkFill = FDH_BULK;             // runs at least this long are stored line by line
 constexpr uint32_t kNoByte = 0x100;  // "no literal seen yet"
+
+// Table entry of this kernel (converted from the device layout of inflate_tables.h while staging):
+//   [1:0]   literal bytes n (0..2)
+//   [6:2]   bits consumed by the whole token (a run: code + extra bits + the 1-bit distance code)
+//   [7] run   [8] end-of-block   [9] bad (cannot occur / invalid)         -> SE_SPECIAL
+//   [13:10] literals: bits of the first literal alone
+//   [31:16] literals: first byte in [23:16], second in [31:24]
+//           runs: length base in [24:16], number of extra bits in [27:25];  zero for the rest
+// The common case -- every running lane looks at a literal entry -- needs only shifts and masks.
+enum : uint32_t { SE_RUN = 0x80, SE_EOB = 0x100, SE_BAD = 0x200, SE_SPECIAL = 0x380 };
+__device__ __forceinline__ uint32_t seg_entry_from(uint32_t e) {
+    const uint32_t nb = e & 15, kind = (e >> 4) & 15;
+    if (kind == K_LIT1) return 1u | (nb << 2) | (nb << 10) | (((e >> 8) & 0xFF) << 16);
+    if (kind == K_LIT2) return 2u | (nb << 2) | (((e >> 24) & 15) << 10) | (((e >> 8) & 0xFFFF) << 16);
+    if (kind == K_LEN) {
+        const uint32_t ex = (e >> 8) & 31, base = e >> 16;
+        return ((nb + ex + 1) << 2) | SE_RUN | (base << 16) | (ex << 25);
+    }
+    if (kind == K_EOB) return (nb << 2) | SE_EOB;
+    return SE_BAD;
+}
+__device__ __forceinline__ uint32_t seg_used(uint32_t e) { return (e >> 2) & 31; }
+// last literal byte of a literal entry (n = 1: [23:16], n = 2: [31:24])
+__device__ __forceinline__ uint32_t seg_lastlit(uint32_t e) { return (e >> (8 + 8 * (e & 3))) & 0xFF; }
 
 // Rings are [word][lane]: any per-lane word index is bank-conflict free.
 struct SegWaveLds {
     uint32_t in_ring[kSegInWords][kWave];
-    uint64_t out_ring[kSegOutWords][kWave];
+    uint32_t out_ring[kSegOutWords][kWave];
 };
 struct SegLds {
     uint32_t lit[kLitSize];
@@ -100,14 +129,15 @@ __device__ __forceinline__ uint4 seg_load16(const uint8_t* p, const uint8_t* lo,
     return seg_load16_edge(p, lo, hi);
 }
 
-// Per-lane sequential bit reader over the lane's input ring.
+// Per-lane sequential bit reader over the lane's input ring.  `lo`/`hi` hold the 64 bits at the
+// read position; the dword after them is fetched from the ring at the start of every step.
 struct SegReader {
     uint32_t* ring;        // &in_ring[0][lane]; word w at ring[w * kWave]
     const uint8_t* gp;     // next 16-B chunk to request from global memory
     const uint8_t* buf_lo;
     const uint8_t* buf_hi;
     uint32_t in_wr, in_rd; // dwords written to / read from the ring
-    uint32_t lo, hi, nextw, boff;
+    uint32_t lo, hi, boff;
     uint4 pend_a, pend_b;  // chunks requested two / one events ago
     bool has_a, has_b;
 
@@ -117,11 +147,6 @@ struct SegReader {
         ring[((in_wr + 2) & (kSegInWords - 1)) * kWave] = v.z;
         ring[((in_wr + 3) & (kSegInWords - 1)) * kWave] = v.w;
         in_wr += 4;
-    }
-    __device__ __forceinline__ uint32_t get() {
-        uint32_t w = ring[(in_rd & (kSegInWords - 1)) * kWave];
-        in_rd++;
-        return w;
     }
     // Positions the reader at stream bit `bit` (relative to the stream's first byte `in`) and
     // primes the whole ring (64 B) synchronously.
@@ -136,33 +161,32 @@ struct SegReader {
             gp += 16;
         }
         in_rd = mis >> 2;
-        lo = get();
-        hi = get();
-        nextw = get();
+        lo = ring[(in_rd & (kSegInWords - 1)) * kWave];
+        hi = ring[((in_rd + 1) & (kSegInWords - 1)) * kWave];
+        in_rd += 2;
         boff = 8 * (mis & 3) + (bit & 7);
     }
-    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(hi, lo, boff); }
-    __device__ __forceinline__ void consume(uint32_t used) {  // used <= 32
-        boff += used;
-        if (boff >= 32) {
-            boff -= 32;
-            lo = hi;
-            hi = nextw;
-            nextw = get();
+    // Synchronous top-up (once, between the window walk and the long counting loop).
+    __device__ __forceinline__ void refill_now() {
+        while ((uint32_t)kSegInWords - (in_wr - in_rd) >= 4u) {
+            put(seg_load16(gp, buf_lo, buf_hi));
+            gp += 16;
         }
     }
-    // Branch-free consume for the hot loops: the ring word is read unconditionally.
-    __device__ __forceinline__ void consume_sel(uint32_t used) {  // used <= 32
-        const uint32_t nw = ring[(in_rd & (kSegInWords - 1)) * kWave];
+    __device__ __forceinline__ uint32_t level() const { return in_wr - in_rd; }  // dwords past lo/hi
+    __device__ __forceinline__ bool starved() const { return in_rd > in_wr; }
+    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(hi, lo, boff); }
+    // the dword that follows lo/hi (read at the start of a step, so its latency hides behind the table look-up)
+    __device__ __forceinline__ uint32_t peek() const { return ring[(in_rd & (kSegInWords - 1)) * kWave]; }
+    // Branch-free advance by `used` (<= 32) bits; nw = peek() from before.
+    __device__ __forceinline__ void advance(uint32_t used, uint32_t nw) {
         boff += used;
         const bool wrap = boff >= 32;
+        boff &= 31;
         lo = wrap ? hi : lo;
-        hi = wrap ? nextw : hi;
-        nextw = wrap ? nw : nextw;
-        boff = wrap ? boff - 32 : boff;
+        hi = wrap ? nw : hi;
         in_rd += wrap ? 1u : 0u;
     }
-    __device__ __forceinline__ bool starved() const { return in_rd > in_wr; }
     // Wavefront-uniform event: commit what was requested two events ago, request the next chunk.
     __device__ __forceinline__ void event(bool want_more) {
         if (has_a) put(pend_a);
@@ -175,95 +199,143 @@ struct SegReader {
             has_b = true;
         }
     }
+    // One event per kSegSteps steps keeps up with 16 B per group; a group can consume up to
+    // kSegSteps * 18 bits = 5 dwords, so denser stretches get extra (waiting) events.
+    __device__ __forceinline__ void events(bool running) {
+        event(running);
+        for (int x = 0; x < 2 && __any(running && level() < 5); x++) event(running);
+    }
 };
 
-// One table look-up, decoded.  n: literal bytes (0..2) in v; run: length of a dist-1 run started
-// by this token; used: stream bits; kind flags.
-struct SegToken {
-    uint32_t used, used1, n, v, run, lastlit;
-    bool is_lit, is_run, is_eob, bad;
+// A run token, resolved: its length and whether its distance code is not the declared one.
+struct SegRun {
+    uint32_t length;
+    bool bad_dist;
 };
-__device__ __forceinline__ SegToken seg_token(const uint32_t* lit, uint32_t win) {
-    SegToken t;
-    const uint32_t e = lit[win & (kLitSize - 1)];
-    const uint32_t nb = e & 15, kind = (e >> 4) & 15;
-    t.is_lit = kind <= K_LIT2;
-    t.is_run = kind == K_LEN;
-    t.is_eob = kind == K_EOB;
-    const uint32_t ex = (e >> 8) & 31;
-    const uint32_t length = (e >> 16) + ((win >> nb) & ((1u << ex) - 1));
-    const uint32_t dbit = (win >> (nb + ex)) & 1;  // the prefix declares one distance code: '0' = 1
-    t.used = nb + (t.is_run ? ex + 1 : 0);
-    t.n = t.is_lit ? kind + 1 : 0;
-    t.v = t.is_lit ? ((e >> 8) & (kind == K_LIT2 ? 0xFFFFu : 0xFFu)) : 0u;  // bytes only for literals
-    t.used1 = e >> 24;  // bits of the first literal alone (literal entries)
-    t.run = t.is_run ? length : 0;
-    t.lastlit = kind == K_LIT2 ? (e >> 16) & 0xFF : (e >> 8) & 0xFF;
-    t.bad = !(t.is_lit || t.is_run || t.is_eob) || (t.is_run && dbit != 0);
-    return t;
+__device__ __forceinline__ SegRun seg_run(uint32_t e, uint32_t win) {
+    const uint32_t used = seg_used(e);
+    const uint32_t ex = (e >> 25) & 7;
+    const uint32_t code_bits = used - ex - 1;
+    SegRun r;
+    r.length = ((e >> 16) & 0x1FF) + ((win >> (code_bits & 31)) & ((1u << ex) - 1));
+    // the prefix declares one distance code: '0' = distance 1; it is the token's last bit
+    r.bad_dist = ((win >> ((used - 1) & 31)) & 1) != 0;
+    return r;
 }
 
-// Counting scan of one lane's chain.  Starts at segment-relative bit `pos`, stops when pos >= stop_at
-// (or at end-of-block / a bad token).  Bytes of tokens that start at or after `count_from` are added to
-// `count`.  `cross` = first position >= kSegWindow the chain stepped on (recorded when
-// RECORD_CROSS).  lastlit = last literal byte seen (kNoByte if none).
+// State of one lane's counting scan.
 struct SegScan {
-    uint32_t pos, count, cross, lastlit;
-    uint32_t stop;  // 0 running/finished normally, 1 end-of-block (pos = its start, eob_bits set), 2 bad
+    uint32_t pos;      // segment-relative bit position of the next token
+    uint32_t count;    // output bytes counted so far
+    uint32_t last_e;   // entry of the last literal token counted (0 if none)
+    uint32_t stop;     // 0 none, 1 end-of-block (pos = its start, eob_bits its length), 2 bad token
     uint32_t eob_bits;
 };
 
-template <bool EVENTS, bool RECORD_CROSS>
-__device__ __forceinline__ uint32_t seg_scan(const uint32_t* lit, SegReader& rd, const uint8_t* in, uint32_t seg_bit0,
-                                         uint32_t in_bits, bool active, uint32_t stop_at, uint32_t count_from,
-                                         SegScan& s) {
-    if (active) rd.start(in, seg_bit0 + s.pos);
+// Walks a chain through the synchronisation window: from s.pos until pos >= kSegWindow (or a stop).
+// GUESS: the chain is only a way to find a synchronisation point -- nothing is counted, and an
+// impossible token (or a stray end-of-block) just means "not synchronised yet": slide on by one
+// bit.  The landing check is what guarantees correctness.  Otherwise (the real chain) every byte
+// is counted.  Close to the window's end a literal pair is taken one literal at a time: the
+// guessed and the real chain may pair literals differently, but they then still cross the window
+// on the same symbol boundary.
+// The freshly primed ring (>= 11 dwords past lo/hi) covers the window (<= 279 bits), so there are
+// no memory events here.
+template <bool GUESS>
+__device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, SegReader& rd,
+                                                    uint32_t limit, bool active, SegScan& s) {
+    bool running = active && s.pos < (uint32_t)kSegWindow;
     uint32_t iter = 0;
-    bool running = active && s.pos < stop_at;
-    // Outer loop = one global-memory event, inner loop = 8 table look-ups that touch neither the
-    // in-flight load registers nor global memory (so the compiler keeps waits and copies out of it).
     while (__any(running)) {
-        if (EVENTS) rd.event(running);
-#pragma unroll 1
-        for (int k = 0; k < 8; k++) {
-            iter++;
-            // straight-line step: every lane looks up; only `running` lanes commit (selects only)
-            SegToken t = seg_token(lit, rd.window());
-            // Close to the window's end a literal pair is taken one literal at a time: the guessed
-            // and the real chain may pair literals differently, but they then still cross the
-            // window on the same symbol boundary.
-            const bool single = t.is_lit && t.n == 2 && s.pos + 24 >= (uint32_t)kSegWindow && s.pos < (uint32_t)kSegWindow;
-            t.used = single ? t.used1 : t.used;
-            t.n = single ? 1u : t.n;
-            t.lastlit = single ? (t.v & 0xFF) : t.lastlit;
-            bool fault = t.bad || (seg_bit0 + s.pos + t.used > in_bits) || rd.starved();
-            if (RECORD_CROSS) {
-                // Inside the window the guessed chain is only a way to find a synchronisation
-                // point: an impossible token (or a stray end-of-block) there just means "not
-                // synchronised yet", so slide on by one bit.  The landing check is what
-                // guarantees correctness.
-                const bool slide = s.pos < (uint32_t)kSegWindow && (t.bad || t.is_eob) && !rd.starved() &&
-                                   seg_bit0 + s.pos + 1 <= in_bits;
-                t.used = slide ? 1u : t.used;
-                t.n = slide ? 0u : t.n;
-                t.run = slide ? 0u : t.run;
-                t.is_lit = slide ? false : t.is_lit;
-                t.is_eob = slide ? false : t.is_eob;
-                fault = slide ? false : fault;
-            }
-            const bool step = running && !fault && !t.is_eob;
-            const bool halt = running && !step;
-            s.stop = halt ? (fault ? 2u : 1u) : s.stop;
-            s.eob_bits = halt ? t.used : s.eob_bits;
-            const bool counted = step && s.pos >= count_from;
-            s.count += counted ? t.n + t.run : 0u;
-            s.lastlit = (counted && t.is_lit) ? t.lastlit : s.lastlit;
-            const uint32_t used = step ? t.used : 0u;
-            s.pos += used;
-            rd.consume_sel(used);
-            if (RECORD_CROSS) s.cross = (s.cross == 0 && s.pos >= (uint32_t)kSegWindow) ? s.pos : s.cross;
-            running = step && s.pos < stop_at;
+        iter++;
+        const uint32_t win = rd.window();
+        const uint32_t e = lit[win & (kLitSize - 1)];
+        const uint32_t nw = rd.peek();
+        uint32_t used = seg_used(e), n = e & 3;
+        const bool is_run = (e & SE_RUN) != 0;
+        bool is_eob = (e & SE_EOB) != 0;
+        bool bad = (e & SE_BAD) != 0;
+        uint32_t run = 0;
+        if (__any(running && is_run)) {
+            const SegRun r = seg_run(e, win);
+            run = is_run ? r.length : 0u;
+            bad = bad || (is_run && r.bad_dist);
         }
+        const bool single = n == 2 && s.pos + 24 >= (uint32_t)kSegWindow;
+        used = single ? (e >> 10) & 15 : used;
+        n = single ? 1u : n;
+        const uint32_t e_lit = single ? (e & 0x00FFFFFCu) | 1u : e;  // the first literal alone
+        if (GUESS) {
+            const bool slide = (bad || is_eob) && s.pos + 1 <= limit;
+            used = slide ? 1u : used;
+            bad = slide ? false : bad;
+            is_eob = slide ? false : is_eob;
+        }
+        const bool fault = bad || s.pos + used > limit;
+        const bool step = running && !fault && !is_eob;
+        const bool halt = running && !step;
+        s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+        s.eob_bits = halt ? used : s.eob_bits;
+        if (!GUESS) {
+            s.count += step ? n + run : 0u;
+            s.last_e = (step && n != 0) ? e_lit : s.last_e;
+        }
+        const uint32_t adv = step ? used : 0u;
+        s.pos += adv;
+        rd.advance(adv, nw);
+        running = step && s.pos < (uint32_t)kSegWindow;
+    }
+    return iter;
+}
+
+// The long loop of pass 1: from s.pos to `stop_at`, counting every byte.
+// Outer loop = one global-memory event, inner loop = kSegSteps look-ups that touch neither the
+// in-flight load registers nor global memory, so the compiler keeps waits and copies out of it.
+// A step is the literal fast path (shifts and masks under the execution mask) unless some running
+// lane looks at a run / end-of-block / impossible entry.
+__device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReader& rd,
+                                                   uint32_t limit, bool active, uint32_t stop_at, SegScan& s) {
+    bool running = active && s.stop == 0 && s.pos < stop_at;
+    uint32_t iter = 0;
+    if (running) rd.refill_now();
+    while (__any(running)) {
+        rd.events(running);
+#pragma unroll 1
+        for (int k = 0; k < kSegSteps; k++) {
+            iter++;
+            const uint32_t win = rd.window();
+            const uint32_t e = lit[win & (kLitSize - 1)];
+            const uint32_t nw = rd.peek();
+            if (!__any(running && (e & SE_SPECIAL) != 0)) {
+                if (running) {  // literals only
+                    const uint32_t used = seg_used(e);
+                    s.count += e & 3;
+                    s.last_e = e;
+                    s.pos += used;
+                    rd.advance(used, nw);
+                    running = s.pos < stop_at;
+                }
+            } else {
+                const uint32_t used = seg_used(e), n = e & 3;
+                const bool is_run = (e & SE_RUN) != 0;
+                const SegRun r = seg_run(e, win);
+                const bool fault = (e & SE_BAD) != 0 || (is_run && r.bad_dist) || s.pos + used > limit;
+                const bool step = running && !fault && (e & SE_EOB) == 0;
+                const bool halt = running && !step;
+                s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+                s.eob_bits = halt ? used : s.eob_bits;
+                s.count += step ? (is_run ? r.length : n) : 0u;
+                s.last_e = (step && n != 0) ? e : s.last_e;
+                const uint32_t adv = step ? used : 0u;
+                s.pos += adv;
+                rd.advance(adv, nw);
+                running = step && s.pos < stop_at;
+            }
+        }
+        // the fast path checks neither of these per step; both are monotone within a group
+        const bool over = s.stop == 0 && (s.pos > limit || rd.starved());
+        s.stop = over ? 2u : s.stop;
+        running = running && !over;
     }
     return iter;
 }
@@ -279,7 +351,11 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     // ---- stream set-up (uniform) ----
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
     const uint64_t o0 = a.out_off[sid], o1 = a.out_off[sid + 1];
+#ifdef FDH_EXP_SAMEIN
+    const uint8_t* in = a.in + a.in_off[sid & 255];  // timing experiment: 256 streams' worth of input
+#else
     const uint8_t* in = a.in + i0;
+#endif
     uint8_t* op = a.out + o0;
     const uint8_t* buf_hi = a.in + a.in_off[a.n];
     const uint64_t ilen = i1 - i0, ocap = o1 - o0;
@@ -287,7 +363,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
                 ilen * 8 >= a.canon_bits + 64ull * kSegMinBits;
     const uint32_t in_bits = (uint32_t)(ilen * 8);
     const uint32_t cap = (uint32_t)ocap;
-    // canonical prefix: lane k compares stream dword k (unaligned loads are fine on gfx950)
+    // canonical prefix: lane k compares stream dword k
     if (ours) {
         bool mismatch = false;
         if (lane < 14) {
@@ -307,6 +383,8 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint32_t data_bits = in_bits - a.canon_bits;
     const uint32_t seg = (data_bits + kWave - 1) / kWave;
     const uint32_t seg_bit0 = a.canon_bits + (uint32_t)lane * seg;  // first bit of this lane's segment
+    const bool in_range = seg_bit0 < in_bits;
+    const uint32_t limit = in_range ? in_bits - seg_bit0 : 0;       // tokens must end at or before this
 
     SegReader rd;
     rd.ring = &W.in_ring[0][lane];
@@ -314,35 +392,39 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     rd.buf_hi = buf_hi;
     rd.gp = in;
     rd.in_wr = rd.in_rd = 0;
-    rd.lo = rd.hi = rd.nextw = rd.boff = 0;
+    rd.lo = rd.hi = rd.boff = 0;
     rd.pend_a = rd.pend_b = make_uint4(0, 0, 0, 0);
     rd.has_a = rd.has_b = false;
 
     // ---- pass 1: guessed chain from bit 0 of the segment; count from where it leaves the window ----
-    SegScan tail;  // the chain from the window's end to the segment's end
+    SegScan tail;  // becomes: the chain from the window's end (x0) to the segment's end
     tail.pos = 0;
     tail.count = 0;
-    tail.cross = 0;
-    tail.lastlit = kNoByte;
+    tail.last_e = 0;
     tail.stop = 0;
     tail.eob_bits = 0;
-    const bool in_range = seg_bit0 < in_bits;
+    if (in_range) rd.start(in, seg_bit0);
     {
-        uint32_t it1 = seg_scan<true, true>(lit, rd, in, seg_bit0, in_bits, in_range, seg, (uint32_t)kSegWindow, tail);
-        (void)it1;
-        SEGDBG(0, it1);
+        uint32_t itw = seg_window_scan<true>(lit, rd, limit, in_range, tail);
+        (void)itw;
+        SEGDBG(6, itw);
         SEGDBG(1, 0);
         SEGDBG(2, 0);
         SEGDBG(3, 0);
         SEGDBG(5, seg);
     }
-    // a chain that stopped inside the window never crossed it
-    uint32_t x0 = tail.cross;  // 0 = did not cross
+    uint32_t x0 = tail.stop == 0 ? tail.pos : 0;  // where the guessed chain left the window (0: it did not)
+    {
+        uint32_t it1 = seg_count_scan(lit, rd, limit, in_range, seg, tail);
+        (void)it1;
+        SEGDBG(0, it1);
+    }
 
     // ---- check: real start from the left neighbour, decode the window, must land on x0 ----
     SegScan head;
-    uint32_t start = 0;           // real chain start of this lane (segment-relative)
-    uint32_t cur_start = ~0u;     // start the current `head` was computed for
+    head.pos = head.count = head.stop = head.eob_bits = head.last_e = 0;
+    uint32_t start = 0;        // real chain start of this lane (segment-relative)
+    uint32_t cur_start = ~0u;  // start the current `head` was computed for
     bool giveup = false;
     for (int round = 0; round < 6; round++) {
         const uint32_t prev_end = __shfl_up(tail.pos, 1, kWave);
@@ -356,44 +438,43 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         if (need) {
             head.pos = start;
             head.count = 0;
-            head.cross = 0;
-            head.lastlit = kNoByte;
+            head.last_e = 0;
             head.stop = 0;
             head.eob_bits = 0;
+            rd.start(in, seg_bit0 + start);
         }
         {
-            uint32_t ith = seg_scan<false, false>(lit, rd, in, seg_bit0, in_bits, need, (uint32_t)kSegWindow, start, head);
+            uint32_t ith = seg_window_scan<false>(lit, rd, limit, need, head);
             (void)ith;
             SEGDBG_ADD(1, ith);
             SEGDBG_ADD(3, 1);
         }
         // landed on the guessed chain?  then the counted tail is the real tail
-        const bool redo = need && (head.stop == 0 ? (head.pos != x0 || x0 == 0) : false);
         const bool stopped_in_head = need && head.stop != 0;
-        if (stopped_in_head) {  // end-of-block / bad token inside the window: no tail
+        const bool redo = need && head.stop == 0 && (head.pos != x0 || x0 == 0);
+        if (stopped_in_head) {  // end-of-block / bad token inside the window: there is no tail
             tail = head;
             tail.count = 0;
+            tail.last_e = 0;
             x0 = head.pos;
         }
-        if (__any(redo)) {  // rare: re-count this segment from the landing point
+        if (__any(redo)) {  // rare: re-count this segment from the landing point (the reader is there)
             if (redo) {
                 tail.pos = head.pos;
                 tail.count = 0;
-                tail.cross = 0;
-                tail.lastlit = kNoByte;
+                tail.last_e = 0;
                 tail.stop = 0;
                 tail.eob_bits = 0;
                 x0 = head.pos;
             }
-            uint32_t itr = seg_scan<true, false>(lit, rd, in, seg_bit0, in_bits, redo, seg, head.pos, tail);
+            uint32_t itr = seg_count_scan(lit, rd, limit, redo, seg, tail);
             (void)itr;
             SEGDBG_ADD(2, itr);
-            SEGDBG_ADD(6, (uint32_t)__popcll(__ballot(redo)));
         }
         if (need) cur_start = start;
     }
     // ---- who is live: lanes up to the first stop on a verified chain ----
-    const bool verified = in_range && cur_start == start && (lane == 0 || true);
+    const bool verified = in_range && cur_start == start;
     const uint64_t stop_mask = __ballot(verified && tail.stop != 0);
     const uint64_t unver_mask = __ballot(!verified);
     const int stop_lane = stop_mask ? __ffsll((unsigned long long)stop_mask) - 1 : kWave;
@@ -403,9 +484,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     // the stream must end with an end-of-block on a verified chain
     bool ok = !giveup && stop_lane < kWave && first_unver > stop_lane && stop_kind == 1;
     // bytes per lane: head (window) + tail
-    const uint32_t head_count = (cur_start == start) ? head.count : 0;
-    const uint32_t count = live ? head_count + tail.count : 0;
-    // a run at the very start of the stream has nothing to repeat (DistanceTooFarBack upstream)
+    const uint32_t count = live ? head.count + tail.count : 0;
     uint32_t incl = count;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
@@ -415,17 +494,15 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint32_t obase = incl - count;
     const uint32_t total = __shfl(incl, kWave - 1, kWave);
     ok = ok && total <= cap;
-    // last literal of every lane's chain -> the byte a leading run of the right neighbour repeats
-    uint32_t own_last = tail.lastlit != kNoByte ? tail.lastlit : ((cur_start == start) ? head.lastlit : kNoByte);
-    if (!live) own_last = kNoByte;
-    uint32_t carry = own_last;
+    // last literal token of every lane's chain -> the byte a leading run of the right neighbour repeats
+    uint32_t carry = live ? (tail.last_e != 0 ? tail.last_e : head.last_e) : 0u;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
         uint32_t y = __shfl_up(carry, o, kWave);
-        if (lane >= o && carry == kNoByte) carry = y;
+        if (lane >= o && carry == 0) carry = y;
     }
-    uint32_t incoming = __shfl_up(carry, 1, kWave);
-    if (lane == 0) incoming = kNoByte;
+    uint32_t last_e = __shfl_up(carry, 1, kWave);  // 0: nothing to repeat yet
+    if (lane == 0) last_e = 0;
     // trailer position: right after the end-of-block symbol
     const uint32_t eob_end = __shfl(seg_bit0 + tail.pos + tail.eob_bits, stop_lane & (kWave - 1), kWave);
     const uint32_t tb = (eob_end + 7) >> 3;
@@ -438,32 +515,39 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     }
 
     // ---- pass 2: decode the real chain again, this time writing ----
+    // Every token on the chain was validated by pass 1 / the check, so nothing is re-checked here
+    // except what pass 1 cannot know: a run with nothing before it.
     const uint32_t my_end = tail.pos;  // chain end (>= seg) or the end-of-block position
     uint32_t pos = start;
-    uint64_t acc = 0;
-    const uint32_t pad = obase & 15;          // bytes in front of this lane's first byte in its 16-B line
+    const uint32_t pad = obase & 15;            // bytes in front of this lane's first byte in its 16-B line
     uint8_t* const line0 = op + (obase - pad);  // 16-B aligned
-    uint32_t vpos = pad & 8;                  // virtual position: multiples of 8 already in the ring
-    uint32_t acc_n = pad & 7;
-    uint32_t vstored = 0;                     // virtual bytes stored to global (multiple of 16)
-    uint32_t ad_a = 0, ad_b = 0, blocks = 0;  // per-lane Adler partial over its own bytes
-    uint32_t fill = 0, last = incoming;
+    uint32_t vposw = pad >> 2;                  // virtual position in dwords: words already in the ring
+    uint32_t acc = 0, sh = 8 * (pad & 3);       // 4-byte accumulator holding sh / 8 bytes (the rest is zero)
+    uint32_t vstored = 0;                       // virtual bytes stored to global (multiple of 16)
+    uint32_t ad_a = 0, ad_b = 0, blocks = 0;    // per-lane Adler partial over its own bytes
+    uint32_t fill = 0;
     bool bad2 = false;
-    uint64_t* const my_out = &W.out_ring[0][lane];
-    if (pad & 8) my_out[0] = 0;               // the skipped qword of the first line
-    const uint32_t vend = pad + count;        // virtual end
+    uint32_t* const my_out = &W.out_ring[0][lane];
+    my_out[0 * kWave] = 0;                      // the words in front of the first byte are pad zeros
+    my_out[1 * kWave] = 0;
+    my_out[2 * kWave] = 0;
+    const uint32_t vend = pad + count;          // virtual end
 
     auto store_piece = [&](uint32_t vs) __attribute__((always_inline)) {  // 16 virtual bytes at vs
-        const uint32_t w = vs >> 3;
-        const uint64_t x0q = my_out[(w & (kSegOutWords - 1)) * kWave];
-        const uint64_t x1q = my_out[((w + 1) & (kSegOutWords - 1)) * kWave];
-        const uint4 q = make_uint4((uint32_t)x0q, (uint32_t)(x0q >> 32), (uint32_t)x1q, (uint32_t)(x1q >> 32));
+        const uint32_t w = vs >> 2;
+        uint4 q;
+        q.x = my_out[((w + 0) & (kSegOutWords - 1)) * kWave];
+        q.y = my_out[((w + 1) & (kSegOutWords - 1)) * kWave];
+        q.z = my_out[((w + 2) & (kSegOutWords - 1)) * kWave];
+        q.w = my_out[((w + 3) & (kSegOutWords - 1)) * kWave];
         if (vs >= pad && vs + 16 <= vend) {
+#ifndef FDH_EXP_NOSTORE
             *reinterpret_cast<uint4*>(line0 + vs) = q;
+#endif
         } else {  // first / last line of this lane: only its own bytes
             for (uint32_t k = 0; k < 16; k++) {
-                if (vs + k >= pad && vs + k < vend)
-                    line0[vs + k] = (uint8_t)((k < 8 ? x0q : x1q) >> (8 * (k & 7)));
+                const uint32_t word = k < 4 ? q.x : (k < 8 ? q.y : (k < 12 ? q.z : q.w));
+                if (vs + k >= pad && vs + k < vend) line0[vs + k] = (uint8_t)(word >> (8 * (k & 3)));
             }
         }
         // Adler-32 partial (pad bytes are zero and come first, so they change nothing)
@@ -481,64 +565,128 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         }
     };
     auto drain = [&]() __attribute__((always_inline)) {
-        while (__any(vpos - vstored >= 16)) {
-            if (vpos - vstored >= 16) {
+        while (__any(4 * vposw - vstored >= 16)) {
+            if (4 * vposw - vstored >= 16) {
                 store_piece(vstored);
                 vstored += 16;
             }
         }
     };
+    // A long dist-1 run (src/decompress.rs:793-801 fills it with one byte): bring the lane to a
+    // 16-B line boundary through the ring, then store whole lines of the byte directly; their
+    // Adler-32 contribution has a closed form.  Called with less than a line waiting in the ring.
+    auto bulk_fill = [&]() __attribute__((always_inline)) {
+        const uint32_t c = seg_lastlit(last_e), c4 = c * 0x01010101u;
+        // complete the accumulator, then whole words up to the line boundary
+        acc |= c4 << sh;
+        my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
+        vposw++;
+        fill -= 4 - (sh >> 3);
+        acc = 0;
+        sh = 0;
+        while (vposw & 3) {
+            my_out[(vposw & (kSegOutWords - 1)) * kWave] = c4;
+            vposw++;
+            fill -= 4;
+        }
+        if (4 * vposw != vstored) {  // exactly one line is waiting in the ring
+            store_piece(vstored);
+            vstored += 16;
+        }
+        uint32_t lines = min(fill, vend - vstored) >> 4;
+        const uint32_t m = lines << 4;
+        const uint4 q = make_uint4(c4, c4, c4, c4);
+        uint8_t* dst = line0 + vstored;
+        for (; lines; lines--, dst += 16) *reinterpret_cast<uint4*>(dst) = q;
+        // m bytes of value c: a' = a + m c ; b' = b + m a + c m (m + 1) / 2
+        ad_a %= kAdlerMod;
+        ad_b %= kAdlerMod;
+        blocks = 0;
+        const uint64_t tri = ((uint64_t)m * (m + 1) / 2) % kAdlerMod;
+        ad_b = (uint32_t)((ad_b + (uint64_t)(m % kAdlerMod) * ad_a + tri * c) % kAdlerMod);
+        ad_a = (uint32_t)((ad_a + (uint64_t)m * c) % kAdlerMod);
+        vstored += m;
+        vposw += m >> 2;
+        fill -= m;
+    };
 
     if (live) rd.start(in, seg_bit0 + pos);
-    bool running = live && (pos < my_end || fill);
+    bool running = live && pos < my_end;
     uint32_t iter = 0;
-    // Outer loop = drain + (every other time) input event; inner loop = 4 straight-line steps.
+    // Outer loop = drain + input event; inner loop = kSegSteps steps (<= 4 B each).
     while (__any(running)) {
         drain();
-        if ((iter & 4) == 0) rd.event(running);
-#pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            iter++;
-            // straight-line step (selects only): a table look-up or 8 bytes of a run
-            const SegToken t = seg_token(lit, rd.window());
-            const bool filling = fill != 0;
-            const bool dec = running && !filling;  // this lane decodes a token now
-            bad2 = bad2 || (dec && (t.bad || t.is_eob || rd.starved() || (t.is_run && last == kNoByte)));
-            const uint32_t nfill = min(fill, 8u);
-            uint64_t vfill = (uint64_t)(last & 0xFF) * 0x0101010101010101ull;
-            vfill = nfill < 8 ? (vfill & ((1ull << (8 * nfill)) - 1)) : vfill;
-            const uint32_t n = running ? (filling ? nfill : t.n) : 0u;
-            const uint64_t v = running ? (filling ? vfill : (uint64_t)t.v) : 0ull;
-            fill = running ? (filling ? fill - nfill : t.run) : fill;
-            last = (dec && t.is_lit) ? t.lastlit : last;
-            const uint32_t used = dec ? t.used : 0u;
-            pos += used;
-            rd.consume_sel(used);
-            // append n bytes; the ring slot at vpos is always free, so the (possibly partial)
-            // accumulator is written there unconditionally and only counts once it is full
-            const uint32_t tot = acc_n + n;
-            acc |= v << (8 * acc_n);
-            const bool full = tot >= 8;
-            my_out[((vpos >> 3) & (kSegOutWords - 1)) * kWave] = acc;
-            vpos += full ? 8u : 0u;
-            const uint64_t spill = acc_n ? (v >> (8 * (8 - acc_n))) : 0ull;
-            acc = full ? spill : acc;
-            acc_n = full ? tot - 8 : tot;
-            running = running && !bad2 && (pos < my_end || fill != 0);
+        if (__any(running && fill >= kSegBulkFill)) {
+            if (running && fill >= kSegBulkFill) bulk_fill();
+            running = running && (pos < my_end || fill != 0);
         }
+        rd.events(running);
+#pragma unroll 1
+        for (int k = 0; k < kSegSteps; k++) {
+            iter++;
+            const uint32_t win = rd.window();
+            const uint32_t e = lit[win & (kLitSize - 1)];
+            const uint32_t nw = rd.peek();
+            if (!__any(running && ((e & SE_SPECIAL) != 0 || fill != 0))) {
+                if (running) {  // literals only: append 1-2 bytes
+                    const uint32_t used = seg_used(e);
+                    pos += used;
+                    rd.advance(used, nw);
+                    last_e = e;
+                    const uint64_t t = (uint64_t)(e >> 16) << sh;
+                    acc |= (uint32_t)t;
+                    // the ring slot at vposw is always free: the (possibly partial) accumulator is
+                    // written there every time and only counts once it is full
+                    my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
+                    const uint32_t tot = sh + ((e & 3) << 3);
+                    const bool full = tot >= 32;
+                    acc = full ? (uint32_t)(t >> 32) : acc;
+                    vposw += full ? 1u : 0u;
+                    sh = tot & 31;
+                    running = pos < my_end;
+                }
+            } else {
+                // general step (selects only): a token of any kind, or 4 bytes of a run in progress
+                const bool filling = fill != 0;
+                const bool dec = running && !filling;  // this lane decodes a token now
+                const bool is_run = (e & SE_RUN) != 0;
+                const SegRun r = seg_run(e, win);
+                const uint32_t n_lit = dec ? e & 3 : 0u;
+                bad2 = bad2 || (dec && ((e & (SE_BAD | SE_EOB)) != 0 || (is_run && (last_e == 0 || r.bad_dist))));
+                last_e = n_lit ? e : last_e;
+                const uint32_t nf = min(fill, 4u);
+                uint32_t vf = seg_lastlit(last_e) * 0x01010101u;
+                vf = nf < 4 ? (vf & ((1u << (8 * nf)) - 1)) : vf;
+                const bool f = running && filling;
+                const uint32_t n = f ? nf : n_lit;
+                const uint32_t v = f ? vf : (n_lit ? e >> 16 : 0u);
+                fill = f ? fill - nf : ((dec && is_run) ? r.length : fill);
+                const uint32_t used = dec ? seg_used(e) : 0u;
+                pos += used;
+                rd.advance(used, nw);
+                const uint64_t t = (uint64_t)v << sh;
+                acc |= (uint32_t)t;
+                my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
+                const uint32_t tot = sh + 8 * n;
+                const bool full = tot >= 32;
+                acc = full ? (uint32_t)(t >> 32) : acc;
+                vposw += full ? 1u : 0u;
+                sh = tot & 31;
+                running = running && !bad2 && (pos < my_end || fill != 0);
+            }
+        }
+        bad2 = bad2 || (live && rd.starved());
+        running = running && !bad2;
     }
+    (void)iter;
     SEGDBG(4, iter);
     SEGDBG(7, total);
     // ---- tail of every lane: the last (partial) line ----
     drain();
     if (live) {
-        // put the loose bytes into the ring as a final qword, then store what is left line by line
-        if (acc_n) {
-            my_out[((vpos >> 3) & (kSegOutWords - 1)) * kWave] = acc;
-            if (((vpos >> 3) & 1) == 0) my_out[(((vpos >> 3) + 1) & (kSegOutWords - 1)) * kWave] = 0;
-        } else if ((vpos - vstored) == 8) {
-            my_out[(((vpos >> 3)) & (kSegOutWords - 1)) * kWave] = 0;
-        }
+        // the loose bytes go into the ring as a final word; zero the rest of that 16-B line
+        my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
+        for (uint32_t w = vposw + 1; (w & 3) != 0; w++) my_out[(w & (kSegOutWords - 1)) * kWave] = 0;
         if (vstored < vend) {
             store_piece(vstored);
             // the last line was summed as 16 bytes; it holds only 16 - z of ours followed by z zeros
@@ -548,11 +696,16 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             ad_b = (ad_b + kAdlerMod - (uint32_t)(((uint64_t)z * ad_a) % kAdlerMod)) % kAdlerMod;
         }
     }
-    const bool wrong_count = live && (vpos + acc_n != vend);
-    SEGDBG(10, (uint32_t)__ballot(bad2));
-    SEGDBG(11, (uint32_t)(__ballot(bad2) >> 32));
-    SEGDBG(12, (uint32_t)__ballot(wrong_count));
-    SEGDBG(13, (uint32_t)(__ballot(wrong_count) >> 32));
+    const bool wrong_count = live && (4 * vposw + (sh >> 3) != vend);
+    {
+        const uint64_t m_bad = __ballot(bad2), m_wrong = __ballot(wrong_count);
+        (void)m_bad;
+        (void)m_wrong;
+        SEGDBG(10, (uint32_t)m_bad);
+        SEGDBG(11, (uint32_t)(m_bad >> 32));
+        SEGDBG(12, (uint32_t)m_wrong);
+        SEGDBG(13, (uint32_t)(m_wrong >> 32));
+    }
     if (__any(bad2 || wrong_count)) {
         if (lane == 0) seg_leave_pending(a, sid);
         return;
@@ -568,6 +721,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint32_t A = (1u + pa) % kAdlerMod;
     const uint32_t B = (uint32_t)(((uint64_t)total + pb) % kAdlerMod);
     const uint32_t adler = (B << 16) | A;
+    SEGDBG(14, adler);
     if (lane == 0) {
         // src/decompress.rs:306-326: byte boundary, then the big-endian Adler-32
         uint32_t stored = ((uint32_t)in[tb] << 24) | ((uint32_t)in[tb + 1] << 16) | ((uint32_t)in[tb + 2] << 8) |
