@@ -215,7 +215,10 @@ __global__ __launch_bounds__(kLaneBlock) void inflate_lanes_kernel(LaneArgs a) {
 
 // Canonical streams, segment-parallel: one stream per wavefront, one segment per lane
 // (inflate_segments.h).
-__global__ __launch_bounds__(kSegWaves* kWave) void inflate_segments_kernel(SegArgs a) {
+#ifndef FDH_SEG_WAVES_PER_SIMD
+#define FDH_SEG_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(kSegWaves* kWave, FDH_SEG_WAVES_PER_SIMD) void inflate_segments_kernel(SegArgs a) {
     __shared__ SegLds lds;
     {  // stage the canonical table, converted to this kernel's entry layout
         const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit);
@@ -297,6 +300,11 @@ __global__ __launch_bounds__(kWave) void build_tables_debug_kernel(const uint8_t
 extern "C" int fdh_debug_read_seg(uint32_t* host) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segdbg), 64 * 16 * 4);
+    return 0;
+}
+extern "C" int fdh_debug_read_segtime(uint32_t* host) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segtime), 4096 * 8 * 4);
     return 0;
 }
 extern "C" int fdh_debug_read(uint32_t* host, uint32_t nwords, int reset) {

@@ -35,16 +35,27 @@ namespace fdh {
 __device__ uint32_t g_segdbg[64 * 16];
 #define SEGDBG(slot, val) do { if (sid < 64 && lane == 0) g_segdbg[sid * 16 + (slot)] = (val); } while (0)
 #define SEGDBG_ADD(slot, val) do { if (sid < 64 && lane == 0) g_segdbg[sid * 16 + (slot)] += (val); } while (0)
+__device__ uint32_t g_segtime[4096 * 8];
+#define SEGTIME(k) do { if (sid < 4096 && lane == 0) g_segtime[sid * 8 + (k)] = (uint32_t)clock64(); } while (0)
 #else
+#define SEGTIME(k) do { } while (0)
 #define SEGDBG(slot, val) do { } while (0)
 #define SEGDBG_ADD(slot, val) do { } while (0)
 #endif
 
-constexpr int kSegWaves = 8;        // wavefronts (= streams) per workgroup: 80 KiB LDS -> 16 wavefronts/CU
-constexpr int kSegInWords = 16;     // per-lane input ring: 16 dwords (64 B)
-constexpr int kSegOutWords = 16;    // per-lane output ring: 16 dwords (64 B)
+#ifndef FDH_SEG_WAVES
+#define FDH_SEG_WAVES 8
+#endif
+#ifndef FDH_SEG_RING
+#define FDH_SEG_RING 16
+#endif
+constexpr int kSegWaves = FDH_SEG_WAVES;   // wavefronts (= streams) per workgroup
+constexpr int kSegInWords = FDH_SEG_RING;  // per-lane input ring, dwords
+constexpr int kSegOutWords = FDH_SEG_RING; // per-lane output ring, dwords
+constexpr int kSegChunk = kSegInWords / 4; // dwords per global load of a lane (a quarter of the ring)
 constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation
-constexpr int kSegSteps = 8;        // table look-ups between two global-memory events
+constexpr int kSegSteps = kSegInWords / 2;  // table look-ups between two global-memory events
+constexpr uint32_t kSegNeed = (kSegSteps * 18 + 31) / 32;  // dwords a group of steps can consume (18 bits/token)
 constexpr uint32_t kSegMinBits = 4 * kSegWindow;  // shorter segments: not worth it -> PENDING
 #ifndef FDH_BULK
 #define FDH_BULK 64
@@ -52,42 +63,45 @@ constexpr uint32_t kSegMinBits = 4 * kSegWindow;  // shorter segments: not worth
 constexpr uint32_t kSegBulkFill = FDH_BULK;             // runs at least this long are stored line by line
 constexpr uint32_t kNoByte = 0x100;  // "no literal seen yet"
 
-// Table entry of this kernel (converted from the device layout of inflate_tables.h while staging):
-//   [1:0]   literal bytes n (0..2)
-//   [6:2]   bits consumed by the whole token (a run: code + extra bits + the 1-bit distance code)
-//   [7] run   [8] end-of-block   [9] bad (cannot occur / invalid)         -> SE_SPECIAL
-//   [13:10] literals: bits of the first literal alone
-//   [31:16] literals: first byte in [23:16], second in [31:24]
-//           runs: length base in [24:16], number of extra bits in [27:25];  zero for the rest
-// The common case -- every running lane looks at a literal entry -- needs only shifts and masks.
-enum : uint32_t { SE_RUN = 0x80, SE_EOB = 0x100, SE_BAD = 0x200, SE_SPECIAL = 0x380 };
+// Table entry of this kernel (converted from the device layout of inflate_tables.h while staging).
+// The fields the hot loops need are whole bytes, so they are used straight from the entry:
+//   byte 0   bits consumed by the whole token [4:0] (a run: code + extra bits + the 1-bit distance
+//            code) | SE_RUN | SE_EOB | SE_BAD (cannot occur / invalid)
+//   byte 1   8 x literal bytes of the token (0, 8, 16)
+//   byte 2-3 literals: first byte, second byte;  runs: length base [24:16], extra-bit count [27:25]
+// The common case -- every running lane looks at a literal entry -- has byte 0 = bits consumed.
+enum : uint32_t { SE_RUN = 0x20, SE_EOB = 0x40, SE_BAD = 0x80, SE_SPECIAL = 0xE0 };
 __device__ __forceinline__ uint32_t seg_entry_from(uint32_t e) {
     const uint32_t nb = e & 15, kind = (e >> 4) & 15;
-    if (kind == K_LIT1) return 1u | (nb << 2) | (nb << 10) | (((e >> 8) & 0xFF) << 16);
-    if (kind == K_LIT2) return 2u | (nb << 2) | (((e >> 24) & 15) << 10) | (((e >> 8) & 0xFFFF) << 16);
+    if (kind == K_LIT1) return nb | (8u << 8) | (((e >> 8) & 0xFF) << 16);
+    if (kind == K_LIT2) return nb | (16u << 8) | (((e >> 8) & 0xFFFF) << 16);
     if (kind == K_LEN) {
         const uint32_t ex = (e >> 8) & 31, base = e >> 16;
-        return ((nb + ex + 1) << 2) | SE_RUN | (base << 16) | (ex << 25);
+        return (nb + ex + 1) | SE_RUN | (base << 16) | (ex << 25);
     }
-    if (kind == K_EOB) return (nb << 2) | SE_EOB;
+    if (kind == K_EOB) return nb | SE_EOB;
     return SE_BAD;
 }
-__device__ __forceinline__ uint32_t seg_used(uint32_t e) { return (e >> 2) & 31; }
-// last literal byte of a literal entry (n = 1: [23:16], n = 2: [31:24])
-__device__ __forceinline__ uint32_t seg_lastlit(uint32_t e) { return (e >> (8 + 8 * (e & 3))) & 0xFF; }
+__device__ __forceinline__ uint32_t seg_used(uint32_t e) { return e & 31; }
+__device__ __forceinline__ uint32_t seg_n8(uint32_t e) { return (e >> 8) & 0xFF; }
+// last literal byte of a literal entry (one literal: byte 2, two: byte 3)
+__device__ __forceinline__ uint32_t seg_lastlit(uint32_t e) { return (e >> (8 + seg_n8(e))) & 0xFF; }
 
-// Rings are [word][lane]: any per-lane word index is bank-conflict free.
-struct SegWaveLds {
-    uint32_t in_ring[kSegInWords][kWave];
-    uint32_t out_ring[kSegOutWords][kWave];
-};
+// Rings are [wavefront][word][lane]: any per-lane word index is bank-conflict free, and with
+// 16 x 64 dwords per ring the slot of (wavefront, lane) and the word index occupy disjoint bits of
+// the element index, so a ring address is one shift and one and-or.
 struct SegLds {
     uint32_t lit[kLitSize];
-    SegWaveLds w[kSegWaves];
+    uint32_t in_ring[kSegWaves * kSegInWords * kWave];
+    uint32_t out_ring[kSegWaves * kSegOutWords * kWave];
 #ifdef FDH_SEG_PAD_LDS
     uint32_t pad[FDH_SEG_PAD_LDS / 4];
 #endif
 };
+static_assert((kSegInWords == 16 || kSegInWords == 8) && kSegOutWords == kSegInWords && kWave == 64, "ring addressing");
+__device__ __forceinline__ uint32_t seg_slot(uint32_t lane_off, uint32_t word) {
+    return lane_off | ((word & (uint32_t)(kSegInWords - 1)) << 6);
+}
 
 struct SegArgs {
     const uint8_t* in;
@@ -115,69 +129,93 @@ __device__ __forceinline__ void seg_leave_pending(const SegArgs& a, uint64_t sid
     }
 }
 
-// 16 bytes from a 16-B aligned address, zero where outside [lo, hi).
-__device__ __attribute__((noinline)) uint4 seg_load16_edge(const uint8_t* p, const uint8_t* lo, const uint8_t* hi) {
-    uint64_t a = 0, b = 0;
-    for (int j = 0; j < 8; j++) {
-        if (p + j >= lo && p + j < hi) a |= (uint64_t)p[j] << (8 * j);
-        if (p + 8 + j >= lo && p + 8 + j < hi) b |= (uint64_t)p[8 + j] << (8 * j);
+// One chunk (kSegChunk dwords) from a chunk-aligned address, zero where outside [lo, hi).
+struct SegChunk {
+    uint32_t w[kSegChunk];
+};
+__device__ __attribute__((noinline)) SegChunk seg_load_edge(const uint8_t* p, const uint8_t* lo, const uint8_t* hi) {
+    SegChunk c;
+    for (int k = 0; k < kSegChunk; k++) {
+        uint32_t v = 0;
+        for (int j = 0; j < 4; j++) {
+            const uint8_t* q = p + 4 * k + j;
+            if (q >= lo && q < hi) v |= (uint32_t)*q << (8 * j);
+        }
+        c.w[k] = v;
     }
-    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    return c;
 }
-__device__ __forceinline__ uint4 seg_load16(const uint8_t* p, const uint8_t* lo, const uint8_t* hi) {
-    if (p >= lo && p + 16 <= hi) return *reinterpret_cast<const uint4*>(p);
-    return seg_load16_edge(p, lo, hi);
+__device__ __forceinline__ SegChunk seg_load(const uint8_t* p, const uint8_t* lo, const uint8_t* hi) {
+    if (p >= lo && p + 4 * kSegChunk <= hi) {
+        SegChunk c;
+        if (kSegChunk == 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p);
+            c.w[0] = v.x;
+            c.w[1] = v.y;
+            c.w[kSegChunk - 2] = v.z;
+            c.w[kSegChunk - 1] = v.w;
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2*>(p);
+            c.w[0] = v.x;
+            c.w[1] = v.y;
+        }
+        return c;
+    }
+    return seg_load_edge(p, lo, hi);
 }
 
 // Per-lane sequential bit reader over the lane's input ring.  `lo`/`hi` hold the 64 bits at the
 // read position; the dword after them is fetched from the ring at the start of every step.
 struct SegReader {
-    uint32_t* ring;        // &in_ring[0][lane]; word w at ring[w * kWave]
+    uint32_t* ring;        // in_ring of the workgroup
+    uint32_t lane_off;     // wavefront * 1024 + lane: this lane's slot for word 0
     const uint8_t* gp;     // next 16-B chunk to request from global memory
     const uint8_t* buf_lo;
     const uint8_t* buf_hi;
     uint32_t in_wr, in_rd; // dwords written to / read from the ring
     uint32_t lo, hi, boff;
-    uint4 pend_a, pend_b;  // chunks requested two / one events ago
+    SegChunk pend_a, pend_b;  // chunks requested two / one events ago
     bool has_a, has_b;
 
-    __device__ __forceinline__ void put(const uint4& v) {
-        ring[((in_wr + 0) & (kSegInWords - 1)) * kWave] = v.x;
-        ring[((in_wr + 1) & (kSegInWords - 1)) * kWave] = v.y;
-        ring[((in_wr + 2) & (kSegInWords - 1)) * kWave] = v.z;
-        ring[((in_wr + 3) & (kSegInWords - 1)) * kWave] = v.w;
-        in_wr += 4;
+    __device__ __forceinline__ void put(const SegChunk& v) {
+#pragma unroll
+        for (int k = 0; k < kSegChunk; k++) ring[seg_slot(lane_off, in_wr + k)] = v.w[k];
+        in_wr += kSegChunk;
     }
     // Positions the reader at stream bit `bit` (relative to the stream's first byte `in`) and
-    // primes the whole ring (64 B) synchronously.
+    // primes the whole ring synchronously.
     __device__ __forceinline__ void start(const uint8_t* in, uint32_t bit) {
         const uint8_t* addr = in + (bit >> 3);
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(addr) & 15);
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(addr) & (4 * kSegChunk - 1));
         gp = addr - mis;
         in_wr = in_rd = 0;
         has_a = has_b = false;
-        for (int k = 0; k < kSegInWords / 4; k++) {
-            put(seg_load16(gp, buf_lo, buf_hi));
-            gp += 16;
+        for (int k = 0; k < kSegInWords / kSegChunk; k++) {
+            put(seg_load(gp, buf_lo, buf_hi));
+            gp += 4 * kSegChunk;
         }
         in_rd = mis >> 2;
-        lo = ring[(in_rd & (kSegInWords - 1)) * kWave];
-        hi = ring[((in_rd + 1) & (kSegInWords - 1)) * kWave];
+        lo = ring[seg_slot(lane_off, in_rd)];
+        hi = ring[seg_slot(lane_off, in_rd + 1)];
         in_rd += 2;
         boff = 8 * (mis & 3) + (bit & 7);
     }
-    // Synchronous top-up (once, between the window walk and the long counting loop).
+    // Synchronous top-up (once, between the window walk and the long counting loop): commits what is
+    // in flight, then loads until the ring is full.
     __device__ __forceinline__ void refill_now() {
-        while ((uint32_t)kSegInWords - (in_wr - in_rd) >= 4u) {
-            put(seg_load16(gp, buf_lo, buf_hi));
-            gp += 16;
+        if (has_a) put(pend_a);
+        if (has_b) put(pend_b);
+        has_a = has_b = false;
+        while ((uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)kSegChunk) {
+            put(seg_load(gp, buf_lo, buf_hi));
+            gp += 4 * kSegChunk;
         }
     }
     __device__ __forceinline__ uint32_t level() const { return in_wr - in_rd; }  // dwords past lo/hi
     __device__ __forceinline__ bool starved() const { return in_rd > in_wr; }
     __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(hi, lo, boff); }
     // the dword that follows lo/hi (read at the start of a step, so its latency hides behind the table look-up)
-    __device__ __forceinline__ uint32_t peek() const { return ring[(in_rd & (kSegInWords - 1)) * kWave]; }
+    __device__ __forceinline__ uint32_t peek() const { return ring[seg_slot(lane_off, in_rd)]; }
     // Branch-free advance by `used` (<= 32) bits; nw = peek() from before.
     __device__ __forceinline__ void advance(uint32_t used, uint32_t nw) {
         boff += used;
@@ -193,17 +231,17 @@ struct SegReader {
         pend_a = pend_b;
         has_a = has_b;
         has_b = false;
-        if (want_more && (uint32_t)kSegInWords - (in_wr - in_rd) >= (has_a ? 8u : 4u)) {
-            pend_b = seg_load16(gp, buf_lo, buf_hi);
-            gp += 16;
+        if (want_more && (uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)(has_a ? 2 * kSegChunk : kSegChunk)) {
+            pend_b = seg_load(gp, buf_lo, buf_hi);
+            gp += 4 * kSegChunk;
             has_b = true;
         }
     }
-    // One event per kSegSteps steps keeps up with 16 B per group; a group can consume up to
-    // kSegSteps * 18 bits = 5 dwords, so denser stretches get extra (waiting) events.
+    // One event per kSegSteps steps keeps up with a chunk per group; a group can consume up to
+    // kSegSteps * 18 bits = kSegNeed dwords, so denser stretches get extra (waiting) events.
     __device__ __forceinline__ void events(bool running) {
         event(running);
-        for (int x = 0; x < 2 && __any(running && level() < 5); x++) event(running);
+        for (int x = 0; x < 2 && __any(running && level() < kSegNeed); x++) event(running);
     }
 };
 
@@ -226,7 +264,7 @@ __device__ __forceinline__ SegRun seg_run(uint32_t e, uint32_t win) {
 // State of one lane's counting scan.
 struct SegScan {
     uint32_t pos;      // segment-relative bit position of the next token
-    uint32_t count;    // output bytes counted so far
+    uint32_t count8;   // 8 x output bytes counted so far
     uint32_t last_e;   // entry of the last literal token counted (0 if none)
     uint32_t stop;     // 0 none, 1 end-of-block (pos = its start, eob_bits its length), 2 bad token
     uint32_t eob_bits;
@@ -238,66 +276,13 @@ struct SegScan {
 // bit.  The landing check is what guarantees correctness.  Otherwise (the real chain) every byte
 // is counted.  Close to the window's end a literal pair is taken one literal at a time: the
 // guessed and the real chain may pair literals differently, but they then still cross the window
-// on the same symbol boundary.
-// The freshly primed ring (>= 11 dwords past lo/hi) covers the window (<= 279 bits), so there are
-// no memory events here.
+// on the same symbol boundary (the length of the first literal alone comes from the canonical
+// table in global memory: this happens two or three times per scan).
 template <bool GUESS>
-__device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, SegReader& rd,
+__device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, const uint32_t* canon_lit, SegReader& rd,
                                                     uint32_t limit, bool active, SegScan& s) {
     bool running = active && s.pos < (uint32_t)kSegWindow;
     uint32_t iter = 0;
-    while (__any(running)) {
-        iter++;
-        const uint32_t win = rd.window();
-        const uint32_t e = lit[win & (kLitSize - 1)];
-        const uint32_t nw = rd.peek();
-        uint32_t used = seg_used(e), n = e & 3;
-        const bool is_run = (e & SE_RUN) != 0;
-        bool is_eob = (e & SE_EOB) != 0;
-        bool bad = (e & SE_BAD) != 0;
-        uint32_t run = 0;
-        if (__any(running && is_run)) {
-            const SegRun r = seg_run(e, win);
-            run = is_run ? r.length : 0u;
-            bad = bad || (is_run && r.bad_dist);
-        }
-        const bool single = n == 2 && s.pos + 24 >= (uint32_t)kSegWindow;
-        used = single ? (e >> 10) & 15 : used;
-        n = single ? 1u : n;
-        const uint32_t e_lit = single ? (e & 0x00FFFFFCu) | 1u : e;  // the first literal alone
-        if (GUESS) {
-            const bool slide = (bad || is_eob) && s.pos + 1 <= limit;
-            used = slide ? 1u : used;
-            bad = slide ? false : bad;
-            is_eob = slide ? false : is_eob;
-        }
-        const bool fault = bad || s.pos + used > limit;
-        const bool step = running && !fault && !is_eob;
-        const bool halt = running && !step;
-        s.stop = halt ? (fault ? 2u : 1u) : s.stop;
-        s.eob_bits = halt ? used : s.eob_bits;
-        if (!GUESS) {
-            s.count += step ? n + run : 0u;
-            s.last_e = (step && n != 0) ? e_lit : s.last_e;
-        }
-        const uint32_t adv = step ? used : 0u;
-        s.pos += adv;
-        rd.advance(adv, nw);
-        running = step && s.pos < (uint32_t)kSegWindow;
-    }
-    return iter;
-}
-
-// The long loop of pass 1: from s.pos to `stop_at`, counting every byte.
-// Outer loop = one global-memory event, inner loop = kSegSteps look-ups that touch neither the
-// in-flight load registers nor global memory, so the compiler keeps waits and copies out of it.
-// A step is the literal fast path (shifts and masks under the execution mask) unless some running
-// lane looks at a run / end-of-block / impossible entry.
-__device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReader& rd,
-                                                   uint32_t limit, bool active, uint32_t stop_at, SegScan& s) {
-    bool running = active && s.stop == 0 && s.pos < stop_at;
-    uint32_t iter = 0;
-    if (running) rd.refill_now();
     while (__any(running)) {
         rd.events(running);
 #pragma unroll 1
@@ -306,17 +291,79 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
             const uint32_t win = rd.window();
             const uint32_t e = lit[win & (kLitSize - 1)];
             const uint32_t nw = rd.peek();
-            if (!__any(running && (e & SE_SPECIAL) != 0)) {
-                if (running) {  // literals only
-                    const uint32_t used = seg_used(e);
-                    s.count += e & 3;
+            uint32_t used = seg_used(e), n8 = seg_n8(e);
+            const bool is_run = (e & SE_RUN) != 0;
+            bool is_eob = (e & SE_EOB) != 0;
+            bool bad = (e & SE_BAD) != 0;
+            uint32_t run = 0;
+            if (__any(running && is_run)) {
+                const SegRun r = seg_run(e, win);
+                run = is_run ? r.length : 0u;
+                bad = bad || (is_run && r.bad_dist);
+            }
+            uint32_t e_lit = e;
+            const bool single = n8 == 16 && s.pos + 24 >= (uint32_t)kSegWindow;
+            if (__any(running && single)) {
+                if (running && single) {
+                    used = canon_lit[win & (kLitSize - 1)] >> 24;  // K_LIT2: bits of the first symbol (inflate_tables.h)
+                    n8 = 8;
+                    e_lit = (e & 0x00FF0000u) | (8u << 8) | used;  // the first literal alone
+                }
+            }
+            if (GUESS) {
+                const bool slide = (bad || is_eob) && s.pos + 1 <= limit;
+                used = slide ? 1u : used;
+                bad = slide ? false : bad;
+                is_eob = slide ? false : is_eob;
+            }
+            const bool fault = bad || s.pos + used > limit;
+            const bool step = running && !fault && !is_eob;
+            const bool halt = running && !step;
+            s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+            s.eob_bits = halt ? used : s.eob_bits;
+            if (!GUESS) {
+                s.count8 += step ? n8 + 8 * run : 0u;
+                s.last_e = (step && n8 != 0) ? e_lit : s.last_e;
+            }
+            const uint32_t adv = step ? used : 0u;
+            s.pos += adv;
+            rd.advance(adv, nw);
+            running = step && s.pos < (uint32_t)kSegWindow;
+        }
+    }
+    return iter;
+}
+
+// The long loop of pass 1: from s.pos to `stop_at`, counting every byte.
+// Outer loop = one global-memory event, inner loop = kSegSteps look-ups that touch neither the
+// in-flight load registers nor global memory, so the compiler keeps waits and copies out of it.
+// A step is the literal fast path (a dozen byte-field operations under the execution mask) unless
+// some running lane looks at a run / end-of-block / impossible entry.  A lane runs while
+// pos < lim; halting sets lim = 0.
+__device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReader& rd, uint32_t limit, bool active,
+                                                   uint32_t stop_at, SegScan& s) {
+    uint32_t lim = (active && s.stop == 0) ? stop_at : 0u;
+    uint32_t iter = 0;
+    if (s.pos < lim) rd.refill_now();
+    while (__any(s.pos < lim)) {
+        rd.events(s.pos < lim);
+#pragma unroll 1
+        for (int k = 0; k < kSegSteps; k++) {
+            iter++;
+            const uint32_t win = rd.window();
+            const uint32_t e = lit[win & (kLitSize - 1)];
+            const uint32_t nw = rd.peek();
+            const uint64_t run_m = __ballot(s.pos < lim), spec_m = __ballot((e & SE_SPECIAL) != 0);
+            if ((run_m & spec_m) == 0) {
+                if (s.pos < lim) {  // literals only: byte 0 = bits, byte 1 = 8 x bytes
+                    s.count8 += (e >> 8) & 0xFF;
                     s.last_e = e;
-                    s.pos += used;
-                    rd.advance(used, nw);
-                    running = s.pos < stop_at;
+                    s.pos += e & 0xFF;
+                    rd.advance(e & 0xFF, nw);
                 }
             } else {
-                const uint32_t used = seg_used(e), n = e & 3;
+                const bool running = s.pos < lim;
+                const uint32_t used = seg_used(e);
                 const bool is_run = (e & SE_RUN) != 0;
                 const SegRun r = seg_run(e, win);
                 const bool fault = (e & SE_BAD) != 0 || (is_run && r.bad_dist) || s.pos + used > limit;
@@ -324,18 +371,18 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
                 const bool halt = running && !step;
                 s.stop = halt ? (fault ? 2u : 1u) : s.stop;
                 s.eob_bits = halt ? used : s.eob_bits;
-                s.count += step ? (is_run ? r.length : n) : 0u;
-                s.last_e = (step && n != 0) ? e : s.last_e;
+                lim = halt ? 0u : lim;
+                s.count8 += step ? (is_run ? 8 * r.length : seg_n8(e)) : 0u;
+                s.last_e = (step && seg_n8(e) != 0) ? e : s.last_e;
                 const uint32_t adv = step ? used : 0u;
                 s.pos += adv;
                 rd.advance(adv, nw);
-                running = step && s.pos < stop_at;
             }
         }
         // the fast path checks neither of these per step; both are monotone within a group
-        const bool over = s.stop == 0 && (s.pos > limit || rd.starved());
+        const bool over = active && s.stop == 0 && (s.pos > limit || rd.starved());
         s.stop = over ? 2u : s.stop;
-        running = running && !over;
+        lim = over ? 0u : lim;
     }
     return iter;
 }
@@ -346,16 +393,16 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint64_t sid = (uint64_t)blockIdx.x * kSegWaves + wid;
     if (sid >= a.n) return;
     const uint32_t* lit = L.lit;
-    SegWaveLds& W = L.w[wid];
+    const uint32_t lane_off = (uint32_t)wid * (kSegInWords * kWave) + (uint32_t)lane;  // ring slot of word 0
 
     // ---- stream set-up (uniform) ----
-    const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
-    const uint64_t o0 = a.out_off[sid], o1 = a.out_off[sid + 1];
 #ifdef FDH_EXP_SAMEIN
-    const uint8_t* in = a.in + a.in_off[sid & 255];  // timing experiment: 256 streams' worth of input
+    const uint64_t i0 = a.in_off[sid & 255], i1 = a.in_off[(sid & 255) + 1];  // timing experiment: L2-resident input
 #else
-    const uint8_t* in = a.in + i0;
+    const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
 #endif
+    const uint64_t o0 = a.out_off[sid], o1 = a.out_off[sid + 1];
+    const uint8_t* in = a.in + i0;
     uint8_t* op = a.out + o0;
     const uint8_t* buf_hi = a.in + a.in_off[a.n];
     const uint64_t ilen = i1 - i0, ocap = o1 - o0;
@@ -387,25 +434,27 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint32_t limit = in_range ? in_bits - seg_bit0 : 0;       // tokens must end at or before this
 
     SegReader rd;
-    rd.ring = &W.in_ring[0][lane];
+    rd.ring = L.in_ring;
+    rd.lane_off = lane_off;
     rd.buf_lo = a.in;
     rd.buf_hi = buf_hi;
     rd.gp = in;
     rd.in_wr = rd.in_rd = 0;
     rd.lo = rd.hi = rd.boff = 0;
-    rd.pend_a = rd.pend_b = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < kSegChunk; k++) rd.pend_a.w[k] = rd.pend_b.w[k] = 0;
     rd.has_a = rd.has_b = false;
 
     // ---- pass 1: guessed chain from bit 0 of the segment; count from where it leaves the window ----
     SegScan tail;  // becomes: the chain from the window's end (x0) to the segment's end
     tail.pos = 0;
-    tail.count = 0;
+    tail.count8 = 0;
     tail.last_e = 0;
     tail.stop = 0;
     tail.eob_bits = 0;
+    SEGTIME(0);
     if (in_range) rd.start(in, seg_bit0);
     {
-        uint32_t itw = seg_window_scan<true>(lit, rd, limit, in_range, tail);
+        uint32_t itw = seg_window_scan<true>(lit, a.canon_lit, rd, limit, in_range, tail);
         (void)itw;
         SEGDBG(6, itw);
         SEGDBG(1, 0);
@@ -413,6 +462,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         SEGDBG(3, 0);
         SEGDBG(5, seg);
     }
+    SEGTIME(1);
     uint32_t x0 = tail.stop == 0 ? tail.pos : 0;  // where the guessed chain left the window (0: it did not)
     {
         uint32_t it1 = seg_count_scan(lit, rd, limit, in_range, seg, tail);
@@ -420,9 +470,10 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         SEGDBG(0, it1);
     }
 
+    SEGTIME(2);
     // ---- check: real start from the left neighbour, decode the window, must land on x0 ----
     SegScan head;
-    head.pos = head.count = head.stop = head.eob_bits = head.last_e = 0;
+    head.pos = head.count8 = head.stop = head.eob_bits = head.last_e = 0;
     uint32_t start = 0;        // real chain start of this lane (segment-relative)
     uint32_t cur_start = ~0u;  // start the current `head` was computed for
     bool giveup = false;
@@ -437,14 +488,14 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         // head: real chain through the window, every byte counted
         if (need) {
             head.pos = start;
-            head.count = 0;
+            head.count8 = 0;
             head.last_e = 0;
             head.stop = 0;
             head.eob_bits = 0;
             rd.start(in, seg_bit0 + start);
         }
         {
-            uint32_t ith = seg_window_scan<false>(lit, rd, limit, need, head);
+            uint32_t ith = seg_window_scan<false>(lit, a.canon_lit, rd, limit, need, head);
             (void)ith;
             SEGDBG_ADD(1, ith);
             SEGDBG_ADD(3, 1);
@@ -454,14 +505,14 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         const bool redo = need && head.stop == 0 && (head.pos != x0 || x0 == 0);
         if (stopped_in_head) {  // end-of-block / bad token inside the window: there is no tail
             tail = head;
-            tail.count = 0;
+            tail.count8 = 0;
             tail.last_e = 0;
             x0 = head.pos;
         }
         if (__any(redo)) {  // rare: re-count this segment from the landing point (the reader is there)
             if (redo) {
                 tail.pos = head.pos;
-                tail.count = 0;
+                tail.count8 = 0;
                 tail.last_e = 0;
                 tail.stop = 0;
                 tail.eob_bits = 0;
@@ -473,6 +524,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         }
         if (need) cur_start = start;
     }
+    SEGTIME(3);
     // ---- who is live: lanes up to the first stop on a verified chain ----
     const bool verified = in_range && cur_start == start;
     const uint64_t stop_mask = __ballot(verified && tail.stop != 0);
@@ -483,17 +535,18 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint32_t stop_kind = __shfl(tail.stop, stop_lane & (kWave - 1), kWave);
     // the stream must end with an end-of-block on a verified chain
     bool ok = !giveup && stop_lane < kWave && first_unver > stop_lane && stop_kind == 1;
-    // bytes per lane: head (window) + tail
-    const uint32_t count = live ? head.count + tail.count : 0;
-    uint32_t incl = count;
+    // bytes per lane: head (window) + tail; summed in 64 bits (a hostile stream can claim anything)
+    const uint32_t count = live ? (head.count8 + tail.count8) >> 3 : 0;
+    unsigned long long incl = count;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
-        uint32_t y = __shfl_up(incl, o, kWave);
+        unsigned long long y = __shfl_up(incl, o, kWave);
         if (lane >= o) incl += y;
     }
-    const uint32_t obase = incl - count;
-    const uint32_t total = __shfl(incl, kWave - 1, kWave);
-    ok = ok && total <= cap;
+    const unsigned long long total64 = __shfl(incl, kWave - 1, kWave);
+    ok = ok && total64 <= cap;
+    const uint32_t total = (uint32_t)total64;
+    const uint32_t obase = (uint32_t)incl - count;
     // last literal token of every lane's chain -> the byte a leading run of the right neighbour repeats
     uint32_t carry = live ? (tail.last_e != 0 ? tail.last_e : head.last_e) : 0u;
 #pragma unroll
@@ -517,7 +570,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     // ---- pass 2: decode the real chain again, this time writing ----
     // Every token on the chain was validated by pass 1 / the check, so nothing is re-checked here
     // except what pass 1 cannot know: a run with nothing before it.
-    const uint32_t my_end = tail.pos;  // chain end (>= seg) or the end-of-block position
+    uint32_t end2 = live ? tail.pos : 0u;  // chain end (>= seg) or the end-of-block position; 0 = halted
     uint32_t pos = start;
     const uint32_t pad = obase & 15;            // bytes in front of this lane's first byte in its 16-B line
     uint8_t* const line0 = op + (obase - pad);  // 16-B aligned
@@ -527,19 +580,19 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     uint32_t ad_a = 0, ad_b = 0, blocks = 0;    // per-lane Adler partial over its own bytes
     uint32_t fill = 0;
     bool bad2 = false;
-    uint32_t* const my_out = &W.out_ring[0][lane];
-    my_out[0 * kWave] = 0;                      // the words in front of the first byte are pad zeros
-    my_out[1 * kWave] = 0;
-    my_out[2 * kWave] = 0;
+    uint32_t* const oring = L.out_ring;
+    oring[seg_slot(lane_off, 0)] = 0;           // the words in front of the first byte are pad zeros
+    oring[seg_slot(lane_off, 1)] = 0;
+    oring[seg_slot(lane_off, 2)] = 0;
     const uint32_t vend = pad + count;          // virtual end
 
     auto store_piece = [&](uint32_t vs) __attribute__((always_inline)) {  // 16 virtual bytes at vs
         const uint32_t w = vs >> 2;
         uint4 q;
-        q.x = my_out[((w + 0) & (kSegOutWords - 1)) * kWave];
-        q.y = my_out[((w + 1) & (kSegOutWords - 1)) * kWave];
-        q.z = my_out[((w + 2) & (kSegOutWords - 1)) * kWave];
-        q.w = my_out[((w + 3) & (kSegOutWords - 1)) * kWave];
+        q.x = oring[seg_slot(lane_off, w + 0)];
+        q.y = oring[seg_slot(lane_off, w + 1)];
+        q.z = oring[seg_slot(lane_off, w + 2)];
+        q.w = oring[seg_slot(lane_off, w + 3)];
         if (vs >= pad && vs + 16 <= vend) {
 #ifndef FDH_EXP_NOSTORE
             *reinterpret_cast<uint4*>(line0 + vs) = q;
@@ -575,17 +628,17 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     // A long dist-1 run (src/decompress.rs:793-801 fills it with one byte): bring the lane to a
     // 16-B line boundary through the ring, then store whole lines of the byte directly; their
     // Adler-32 contribution has a closed form.  Called with less than a line waiting in the ring.
-    auto bulk_fill = [&]() __attribute__((always_inline)) {
-        const uint32_t c = seg_lastlit(last_e), c4 = c * 0x01010101u;
+    auto bulk_fill = [&](uint32_t c) __attribute__((always_inline)) {
+        const uint32_t c4 = c * 0x01010101u;
         // complete the accumulator, then whole words up to the line boundary
         acc |= c4 << sh;
-        my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
+        oring[seg_slot(lane_off, vposw)] = acc;
         vposw++;
         fill -= 4 - (sh >> 3);
         acc = 0;
         sh = 0;
         while (vposw & 3) {
-            my_out[(vposw & (kSegOutWords - 1)) * kWave] = c4;
+            oring[seg_slot(lane_off, vposw)] = c4;
             vposw++;
             fill -= 4;
         }
@@ -610,83 +663,87 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         fill -= m;
     };
 
+    SEGTIME(4);
     if (live) rd.start(in, seg_bit0 + pos);
-    bool running = live && pos < my_end;
     uint32_t iter = 0;
+    // A lane runs while pos < end2 or a run is being filled.
     // Outer loop = drain + input event; inner loop = kSegSteps steps (<= 4 B each).
-    while (__any(running)) {
+    while (__any(pos < end2 || fill != 0)) {
         drain();
-        if (__any(running && fill >= kSegBulkFill)) {
-            if (running && fill >= kSegBulkFill) bulk_fill();
-            running = running && (pos < my_end || fill != 0);
+        if (__any(fill >= kSegBulkFill)) {
+            if (fill >= kSegBulkFill) bulk_fill(seg_lastlit(last_e));
         }
-        rd.events(running);
+        rd.events(pos < end2 || fill != 0);
 #pragma unroll 1
         for (int k = 0; k < kSegSteps; k++) {
             iter++;
             const uint32_t win = rd.window();
             const uint32_t e = lit[win & (kLitSize - 1)];
             const uint32_t nw = rd.peek();
-            if (!__any(running && ((e & SE_SPECIAL) != 0 || fill != 0))) {
-                if (running) {  // literals only: append 1-2 bytes
-                    const uint32_t used = seg_used(e);
-                    pos += used;
-                    rd.advance(used, nw);
+            const uint64_t run_m = __ballot(pos < end2), spec_m = __ballot((e & SE_SPECIAL) != 0);
+            const uint64_t fill_m = __ballot(fill != 0);
+            if (((run_m & spec_m) | fill_m) == 0) {
+                if (pos < end2) {  // literals only: append 1-2 bytes
+                    pos += e & 0xFF;
+                    rd.advance(e & 0xFF, nw);
                     last_e = e;
                     const uint64_t t = (uint64_t)(e >> 16) << sh;
                     acc |= (uint32_t)t;
                     // the ring slot at vposw is always free: the (possibly partial) accumulator is
                     // written there every time and only counts once it is full
-                    my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
-                    const uint32_t tot = sh + ((e & 3) << 3);
+                    oring[seg_slot(lane_off, vposw)] = acc;
+                    const uint32_t tot = sh + ((e >> 8) & 0xFF);
                     const bool full = tot >= 32;
                     acc = full ? (uint32_t)(t >> 32) : acc;
                     vposw += full ? 1u : 0u;
                     sh = tot & 31;
-                    running = pos < my_end;
                 }
             } else {
                 // general step (selects only): a token of any kind, or 4 bytes of a run in progress
                 const bool filling = fill != 0;
-                const bool dec = running && !filling;  // this lane decodes a token now
+                const bool dec = !filling && pos < end2;  // this lane decodes a token now
                 const bool is_run = (e & SE_RUN) != 0;
                 const SegRun r = seg_run(e, win);
-                const uint32_t n_lit = dec ? e & 3 : 0u;
-                bad2 = bad2 || (dec && ((e & (SE_BAD | SE_EOB)) != 0 || (is_run && (last_e == 0 || r.bad_dist))));
-                last_e = n_lit ? e : last_e;
+                const uint32_t n8_lit = dec ? seg_n8(e) : 0u;
+                const bool bad_now = dec && ((e & (SE_BAD | SE_EOB)) != 0 || (is_run && (last_e == 0 || r.bad_dist)));
+                bad2 = bad2 || bad_now;
+                last_e = n8_lit ? e : last_e;
                 const uint32_t nf = min(fill, 4u);
                 uint32_t vf = seg_lastlit(last_e) * 0x01010101u;
                 vf = nf < 4 ? (vf & ((1u << (8 * nf)) - 1)) : vf;
-                const bool f = running && filling;
-                const uint32_t n = f ? nf : n_lit;
-                const uint32_t v = f ? vf : (n_lit ? e >> 16 : 0u);
-                fill = f ? fill - nf : ((dec && is_run) ? r.length : fill);
+                const uint32_t n8 = filling ? 8 * nf : n8_lit;
+                const uint32_t v = filling ? vf : (n8_lit ? e >> 16 : 0u);
+                fill = filling ? fill - nf : ((dec && is_run && !bad_now) ? r.length : 0u);
                 const uint32_t used = dec ? seg_used(e) : 0u;
                 pos += used;
                 rd.advance(used, nw);
+                end2 = bad_now ? 0u : end2;
                 const uint64_t t = (uint64_t)v << sh;
                 acc |= (uint32_t)t;
-                my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
-                const uint32_t tot = sh + 8 * n;
+                oring[seg_slot(lane_off, vposw)] = acc;
+                const uint32_t tot = sh + n8;
                 const bool full = tot >= 32;
                 acc = full ? (uint32_t)(t >> 32) : acc;
                 vposw += full ? 1u : 0u;
                 sh = tot & 31;
-                running = running && !bad2 && (pos < my_end || fill != 0);
             }
         }
-        bad2 = bad2 || (live && rd.starved());
-        running = running && !bad2;
+        if (live && rd.starved()) {  // cannot happen (events() keeps the ring ahead); stop rather than decode garbage
+            bad2 = true;
+            end2 = 0;
+            fill = 0;
+        }
     }
     (void)iter;
+    SEGTIME(5);
     SEGDBG(4, iter);
     SEGDBG(7, total);
     // ---- tail of every lane: the last (partial) line ----
     drain();
     if (live) {
         // the loose bytes go into the ring as a final word; zero the rest of that 16-B line
-        my_out[(vposw & (kSegOutWords - 1)) * kWave] = acc;
-        for (uint32_t w = vposw + 1; (w & 3) != 0; w++) my_out[(w & (kSegOutWords - 1)) * kWave] = 0;
+        oring[seg_slot(lane_off, vposw)] = acc;
+        for (uint32_t w = vposw + 1; (w & 3) != 0; w++) oring[seg_slot(lane_off, w)] = 0;
         if (vstored < vend) {
             store_piece(vstored);
             // the last line was summed as 16 bytes; it holds only 16 - z of ours followed by z zeros
@@ -722,6 +779,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint32_t B = (uint32_t)(((uint64_t)total + pb) % kAdlerMod);
     const uint32_t adler = (B << 16) | A;
     SEGDBG(14, adler);
+    SEGTIME(6);
     if (lane == 0) {
         // src/decompress.rs:306-326: byte boundary, then the big-endian Adler-32
         uint32_t stored = ((uint32_t)in[tb] << 24) | ((uint32_t)in[tb + 1] << 16) | ((uint32_t)in[tb + 2] << 8) |
