@@ -302,6 +302,12 @@ extern "C" int fdh_debug_read_seg(uint32_t* host) {
     hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segdbg), 64 * 16 * 4);
     return 0;
 }
+extern "C" int fdh_debug_read_gstat(unsigned long long* host, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_gstat), 16 * 8);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_gstat), z, 16 * 8); }
+    return 0;
+}
 extern "C" int fdh_debug_read_segtime(uint32_t* host) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segtime), 4096 * 8 * 4);

@@ -32,7 +32,7 @@ constexpr int kInRingDw = 2 * kInChunk / 4; // two chunks
 constexpr int kOutRing = 4096;              // bytes, power of two
 constexpr int kOutMask = kOutRing - 1;
 constexpr int kFlushSlack = 64;
-constexpr int kMaxMatches = 128;            // match tokens replayed per tile
+constexpr int kMaxMatches = 256;            // match tokens replayed per tile
 constexpr int kTileBits = 64;               // stream bits owned by one lane of a tile
 
 // Decode tables of the current block.
@@ -81,6 +81,10 @@ enum : uint32_t { RC_OK = 0, RC_EOB = 0x100, RC_STUCK = 0x101 };  // anything el
 #ifdef FDH_DEBUG_TILES
 __device__ uint32_t g_dbg[1 << 16];
 __device__ uint32_t g_dbg_n;
+__device__ unsigned long long g_gstat[16];
+#define GSTAT(k, v) do { if (lane == 0) atomicAdd(&g_gstat[k], (unsigned long long)(v)); } while (0)
+#else
+#define GSTAT(k, v) do { } while (0)
 #endif
 
 // Stores output [flushed, target) to global memory and folds it into the Adler-32.  target is
@@ -602,10 +606,29 @@ struct Inflater {
             uint32_t hi = vsel(a, w1, vsel(b, w2, w3));
             return __builtin_amdgcn_alignbit(hi, lo, p & 31);
         };
+        // Table entries with codes beyond the primary index resolved by a per-lane canonical walk
+        // (the reference's secondary tables, src/huffman.rs:138-181): the result is the entry the
+        // symbol would have had in a wide enough primary table.
+        auto lit_at = [&](uint32_t w) __attribute__((always_inline)) -> uint32_t {
+            uint32_t e = T.lit[w & (kLitSize - 1)];
+            if (((e >> 4) & 15) == K_LONG) {
+                uint32_t sym, len;
+                if (long_walk(T.lit_cb, T.lit_sorted, w, kLitBits + 1, sym, len)) e = LitlenTraits::entry(sym, len);
+            }
+            return e;
+        };
+        auto dist_at = [&](uint32_t v) __attribute__((always_inline)) -> uint32_t {
+            uint32_t de = T.dist[v & (kDistSize - 1)];
+            if (((de >> 4) & 15) == D_LONG) {
+                uint32_t sym, len;
+                if (long_walk(T.dist_cb, T.dist_sorted, v, kDistBits + 1, sym, len)) de = DistTraits::entry(sym, len);
+            }
+            return de;
+        };
         // Decodes the token at chunk bit p.  kind: 0 literal(s), 1 match, 2 end-of-block, 3 bad.
         // adv1: bits of the first symbol; adv: bits of the whole table entry / token.
         auto token = [&](uint32_t p, uint32_t& kind, uint32_t& adv1, uint32_t& adv) __attribute__((always_inline)) {
-            uint32_t e = T.lit[bits32(p) & (kLitSize - 1)];
+            uint32_t e = lit_at(bits32(p));
             uint32_t nb = e & 15, k = (e >> 4) & 15;
             if (k <= K_LIT2) {
                 kind = 0;
@@ -613,7 +636,7 @@ struct Inflater {
                 adv = nb;
             } else if (k == K_LEN) {
                 uint32_t t = nb + ((e >> 8) & 31);
-                uint32_t de = T.dist[bits32(p + t) & (kDistSize - 1)];
+                uint32_t de = dist_at(bits32(p + t));
                 kind = (((de >> 4) & 15) == D_DIST) ? 1 : 3;
                 adv = t + (de & 15) + ((de >> 8) & 15);
                 adv1 = adv;
@@ -627,6 +650,12 @@ struct Inflater {
             if ((int32_t)(p + adv) > la) kind = 3;  // token (or literal pair) not fully inside the input
         };
 
+#ifdef FDH_DEBUG_TILES
+        long long tq = clock64();
+#define TPHASE(k) do { long long tn = clock64(); GSTAT(k, tn - tq); tq = tn; } while (0)
+#else
+#define TPHASE(k) do { } while (0)
+#endif
         // ---- pass 1: speculative chain from chunk bit 0 (lane 0's start is a real boundary) ----
         uint64_t mask = 0, mmask = 0;   // symbol starts / match starts inside [start, 64)
         uint32_t start = 0, endp = 0;   // chain start, chain end (>= 64 when it left the chunk)
@@ -657,12 +686,16 @@ struct Inflater {
             }
             endp = p;
         }
+        TPHASE(10);
         // ---- synchronisation: hand every lane the real start of its chain ----
         // A lane whose predecessor's chain currently stops (end-of-block / bad token, possibly on
         // a still-speculative chain) has no start to take over and sits the iteration out.  At
         // exit every lane up to the first stop holds the true chain (induction from lane 0).
         bool converged = false;
         for (int iter = 0; iter < 2 * kWave; iter++) {
+#ifdef FDH_DEBUG_TILES
+            GSTAT(6, 1);  // synchronisation iterations
+#endif
             uint32_t prev_end = __shfl_up(endp, 1, kWave);
             uint32_t prev_stop = __shfl_up(stop, 1, kWave);
             uint32_t in_start = prev_end - kTileBits;
@@ -709,6 +742,7 @@ struct Inflater {
                 start = in_start;
             }
         }
+        TPHASE(11);
         if (!converged) return RC_OK;  // pathological input: the serial decoder decides
         const uint64_t stopped = __ballot(stop != 0);
         const int stop_lane = stopped ? __ffsll((unsigned long long)stopped) - 1 : kWave;
@@ -724,7 +758,7 @@ struct Inflater {
             while (mm) {
                 uint32_t p = (uint32_t)__builtin_ctzll(mm);
                 mm &= mm - 1;
-                uint32_t e = T.lit[bits32(p) & (kLitSize - 1)];
+                uint32_t e = lit_at(bits32(p));
                 uint32_t lcb = e & 15, lex = (e >> 8) & 31;
                 uint32_t length = (e >> 16) + ((bits32(p + lcb)) & ((1u << lex) - 1));
                 count += length - 1;
@@ -752,6 +786,7 @@ struct Inflater {
         const uint32_t total_packed = __shfl(incl, last_lane, kWave);
         const uint32_t total = total_packed & 0xFFFFF, nmatch = total_packed >> 20;
 
+        TPHASE(12);
         // ---- emit literals, list matches ----
         wave_sync();
         if (emit) {
@@ -761,7 +796,7 @@ struct Inflater {
             while (m) {
                 uint32_t p = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
-                uint32_t e = T.lit[bits32(p) & (kLitSize - 1)];
+                uint32_t e = lit_at(bits32(p));
                 uint32_t k = (e >> 4) & 15;
                 if (k <= K_LIT2) {
                     io.out_ring[opo & kOutMask] = (uint8_t)(e >> 8);
@@ -776,7 +811,7 @@ struct Inflater {
                     uint32_t lcb = e & 15, lex = (e >> 8) & 31;
                     uint32_t length = (e >> 16) + (bits32(p + lcb) & ((1u << lex) - 1));
                     uint32_t dv = bits32(p + lcb + lex);
-                    uint32_t de = T.dist[dv & (kDistSize - 1)];
+                    uint32_t de = dist_at(dv);
                     uint32_t dcb = de & 15, dex = (de >> 8) & 15;
                     uint32_t dist = (de >> 16) + ((dv >> dcb) & ((1u << dex) - 1));
                     io.mlist[2 * mi] = (opo - gmis - opos) | (length << 16);
@@ -787,15 +822,51 @@ struct Inflater {
             }
         }
         wave_sync();
-        // ---- replay matches in stream order (sources are final by then) ----
+        TPHASE(13);
+        GSTAT(15, nmatch);
+        // ---- matches ----
+        // Short matches whose source lies wholly in front of the ring window read final bytes from
+        // global memory: they depend on nothing in this tile, so up to 64 of them are copied at once
+        // (one lane each) instead of one global round trip per match.
+        {
+            const uint32_t ring_top = opos + total;
+            const int64_t ring_lo = (int64_t)ring_top - kOutRing;
+            for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                const bool mine = j < nmatch;
+                const uint32_t m0 = mine ? io.mlist[2 * j] : 0u, dist = mine ? io.mlist[2 * j + 1] : 1u;
+                const uint32_t at = opos + (m0 & 0xFFFF), length = m0 >> 16;
+                if (__any(mine && dist > at)) return ST_DISTANCE_TOO_FAR_BACK;  // src/decompress.rs:782
+                const bool far = mine && length <= 16 && (int64_t)at - (int64_t)dist + (int64_t)length <= ring_lo;
+                if (__any(far)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our own flush stores
+                    uint32_t b[16];
+                    const uint8_t* src = out_al + gmis + (at - dist);  // dist >= length here
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) {
+                        b[k] = 0;
+                        // L1-bypassing load: the line may have been cached before our later stores
+                        if (far && k < length) b[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) {
+                        if (far && k < length) io.out_ring[(at + k + gmis) & kOutMask] = (uint8_t)b[k];
+                    }
+                    if (far) io.mlist[2 * j] = m0 & 0xFFFF;  // length 0: done
+                }
+            }
+            wave_sync();
+        }
+        // ---- replay the other matches in stream order (sources are final by then) ----
         for (uint32_t j = 0; j < nmatch; j++) {
             uint32_t m0 = uni(io.mlist[2 * j]), dist = uni(io.mlist[2 * j + 1]);
             uint32_t at = opos + (m0 & 0xFFFF), length = m0 >> 16;
-            if (dist > at) return ST_DISTANCE_TOO_FAR_BACK;  // src/decompress.rs:782
+            if (length == 0) continue;
             copy_bytes(at, length, dist, opos + total);
             wave_sync();
         }
-#ifdef FDH_DEBUG_TILES
+        TPHASE(14);
+#ifdef FDH_DEBUG_TILES_TRACE
         {
             uint32_t slot = g_dbg_n;  // single-stream debugging only
             uint32_t* d = g_dbg + 8 + slot * 264;
@@ -843,13 +914,31 @@ struct Inflater {
         for (;;) {
             if (TILES && serial_credit == 0 && opos < cap) {
                 uint32_t progress;
+#ifdef FDH_DEBUG_TILES
+                const long long t0 = clock64();
+#endif
                 uint32_t rc = tile_step(progress);
+#ifdef FDH_DEBUG_TILES
+                GSTAT(0, 1);
+                GSTAT(1, progress);
+                GSTAT(2, clock64() - t0);
+                if (progress < 16 * kTileBits) GSTAT(5, 1);
+#endif
                 if (rc != RC_OK) return rc;
                 // a tile that got stuck early: let the serial decoder clear the obstacle
                 if (progress < 16 * kTileBits) serial_credit = progress == 0 ? 4 : 1;
                 if (progress) continue;
             }
+#ifdef FDH_DEBUG_TILES
+            const long long t1 = clock64();
+            const uint64_t c0 = consumed_bits();
+#endif
             uint32_t rc = serial_token();
+#ifdef FDH_DEBUG_TILES
+            GSTAT(3, 1);
+            GSTAT(4, clock64() - t1);
+            GSTAT(7, consumed_bits() - c0);
+#endif
             if (rc != RC_OK) return rc;
             if (serial_credit) serial_credit--;
         }
@@ -898,7 +987,14 @@ struct Inflater {
         if (!START_IN_BLOCK) rc = parse_zlib_header();
         while (rc == RC_OK) {
             if (!START_IN_BLOCK) {
+#ifdef FDH_DEBUG_TILES
+                const long long th = clock64();
+#endif
                 rc = parse_block_header();
+#ifdef FDH_DEBUG_TILES
+                GSTAT(8, clock64() - th);
+                GSTAT(9, 1);
+#endif
                 if (rc == RC_OK) rc = decode_block_data<TILES>();
             } else {
                 rc = decode_block_data<TILES>();

@@ -194,4 +194,21 @@ __device__ __forceinline__ void long_decode(const CodeBook& cb, const uint16_t* 
     }
 }
 
+// Per-lane variant for codes longer than the primary index (lengths min_len..15): `w` holds the
+// next >= 15 stream bits of this lane, LSB first.  False if no code matches (cannot happen for a
+// complete code).
+__device__ __forceinline__ bool long_walk(const CodeBook& cb, const uint16_t* sorted, uint32_t w, int min_len,
+                                          uint32_t& sym, uint32_t& nbits) {
+    const uint32_t r = __brev(w);  // canonical codes are compared MSB first
+    for (int len = min_len; len <= 15; len++) {
+        const uint32_t d = (r >> (32 - len)) - cb.first[len];
+        if (d < cb.hist[len]) {
+            sym = sorted[cb.offs[len] + d];
+            nbits = (uint32_t)len;
+            return true;
+        }
+    }
+    return false;
+}
+
 }  // namespace fdh
