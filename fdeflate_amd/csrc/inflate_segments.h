@@ -166,6 +166,8 @@ __device__ __forceinline__ SegChunk seg_load(const uint8_t* p, const uint8_t* lo
 
 // Per-lane sequential bit reader over the lane's input ring.  `lo`/`hi` hold the 64 bits at the
 // read position; the dword after them is fetched from the ring at the start of every step.
+// The reader sits TWO BITS IN FRONT of the next token: bits [13:2] of the raw 32-bit window are the
+// 12 table-index bits, so `raw & 0x3ffc` is the byte offset of the table entry (one instruction).
 struct SegReader {
     uint32_t* ring;        // in_ring of the workgroup
     uint32_t lane_off;     // wavefront * 1024 + lane: this lane's slot for word 0
@@ -185,6 +187,7 @@ struct SegReader {
     // Positions the reader at stream bit `bit` (relative to the stream's first byte `in`) and
     // primes the whole ring synchronously.
     __device__ __forceinline__ void start(const uint8_t* in, uint32_t bit) {
+        bit -= 2;  // see above; every start lies behind the stream's 53-byte prefix
         const uint8_t* addr = in + (bit >> 3);
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(addr) & (4 * kSegChunk - 1));
         gp = addr - mis;
@@ -213,7 +216,8 @@ struct SegReader {
     }
     __device__ __forceinline__ uint32_t level() const { return in_wr - in_rd; }  // dwords past lo/hi
     __device__ __forceinline__ bool starved() const { return in_rd > in_wr; }
-    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(hi, lo, boff); }
+    __device__ __forceinline__ uint32_t raw_window() const { return __builtin_amdgcn_alignbit(hi, lo, boff); }
+    __device__ __forceinline__ uint32_t window() const { return raw_window() >> 2; }  // 30 stream bits
     // the dword that follows lo/hi (read at the start of a step, so its latency hides behind the table look-up)
     __device__ __forceinline__ uint32_t peek() const { return ring[seg_slot(lane_off, in_rd)]; }
     // Branch-free advance by `used` (<= 32) bits; nw = peek() from before.
@@ -334,6 +338,148 @@ __device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, const u
     return iter;
 }
 
+// Byte offset of an LDS object inside the workgroup's LDS allocation.
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// Up to `left` literal-only steps of the counting loop, hand-scheduled.  The choice of
+// instructions follows their measured issue cost on gfx950 (two cycles per wavefront for plain
+// VOP2, four for VOP3 / compares / scalar instructions): the table entry's fields are whole
+// bytes, the entry itself is summed (byte 1 of the sum = 8 x bytes), the ring address is kept as
+// an LDS byte address, and the word hand-over at a dword boundary runs under the execution mask.
+// Stops in front of a step in which some running lane looks at a special entry and returns the
+// number of steps still to do (that step included); nothing of that step has been applied.
+// Requires the literal table at LDS offset 0.
+__device__ __forceinline__ uint32_t seg_count_group(uint32_t left, uint32_t lim, uint32_t ring_base, SegReader& rd,
+                                                    uint32_t& pos, uint32_t& gsum, uint32_t& last_e) {
+    static_assert(kSegInWords == 16, "ring word mask 0xf00 below");
+    uint32_t ra = ring_base | ((rd.in_rd << 8) & 0xf00u);
+    uint32_t w2, e, nw, t;
+    uint64_t sv;
+    asm volatile(
+        "Lstep_%=:\n"
+        "  v_alignbit_b32 %[w2], %[hi], %[lo], %[b]\n"
+        "  v_and_b32 %[t], 0x3ffc, %[w2]\n"
+        "  ds_read_b32 %[e], %[t]\n"
+        "  ds_read_b32 %[nw], %[ra]\n"
+        "  v_cmp_lt_u32 vcc, %[pos], %[lim]\n"
+        "  s_and_saveexec_b64 %[sv], vcc\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        "  v_and_b32 %[t], 0xe0, %[e]\n"
+        "  v_cmp_ne_u32 vcc, 0, %[t]\n"
+        "  s_cbranch_vccnz Lspecial_%=\n"
+        "  v_and_b32 %[t], 0xff, %[e]\n"
+        "  v_add_u32 %[gsum], %[gsum], %[e]\n"
+        "  v_mov_b32 %[last], %[e]\n"
+        "  v_add_u32 %[pos], %[pos], %[t]\n"
+        "  v_add_u32 %[b], %[b], %[t]\n"
+        "  v_cmp_lt_u32 vcc, 31, %[b]\n"
+        "  v_and_b32 %[b], 31, %[b]\n"
+        "  s_and_b64 exec, exec, vcc\n"
+        "  s_waitcnt lgkmcnt(0)\n"
+        "  v_mov_b32 %[lo], %[hi]\n"
+        "  v_mov_b32 %[hi], %[nw]\n"
+        "  v_add_u32 %[t], 0x100, %[ra]\n"
+        "  v_and_b32 %[t], 0xf00, %[t]\n"
+        "  v_or_b32 %[ra], %[rb], %[t]\n"
+        "  v_add_u32 %[ird], 1, %[ird]\n"
+        "  s_mov_b64 exec, %[sv]\n"
+        "  s_sub_u32 %[left], %[left], 1\n"
+        "  s_cmp_lg_u32 %[left], 0\n"
+        "  s_cbranch_scc1 Lstep_%=\n"
+        "  s_branch Ldone_%=\n"
+        "Lspecial_%=:\n"
+        "  s_mov_b64 exec, %[sv]\n"
+        "Ldone_%=:\n"
+        "  s_waitcnt lgkmcnt(0)\n"
+        : [left] "+s"(left), [pos] "+v"(pos), [gsum] "+v"(gsum), [last] "+v"(last_e), [lo] "+v"(rd.lo),
+          [hi] "+v"(rd.hi), [b] "+v"(rd.boff), [ra] "+v"(ra), [ird] "+v"(rd.in_rd), [w2] "=&v"(w2), [e] "=&v"(e),
+          [nw] "=&v"(nw), [t] "=&v"(t), [sv] "=&s"(sv)
+        : [lim] "v"(lim), [rb] "v"(ring_base)
+        : "vcc", "scc", "memory");
+    return left;
+}
+
+// Up to `left` literal-only steps of the writing loop (pass 2), hand-scheduled like
+// seg_count_group: decode one entry, append its 1-2 bytes to the 4-byte accumulator, keep the
+// (possibly partial) accumulator in the output ring, move on to the next ring word when it is full.
+// Entered only while no lane is filling a run.  Returns the steps still to do when some running
+// lane meets a special entry (nothing of that step applied).
+struct SegWriter {
+    uint32_t acc, sh, vposw;
+};
+__device__ __forceinline__ uint32_t seg_write_group(uint32_t left, uint32_t end2, uint32_t ring_base, uint32_t out_base,
+                                                    SegReader& rd, SegWriter& wr, uint32_t& pos, uint32_t& last_e) {
+    static_assert(kSegInWords == 16 && kSegOutWords == 16, "ring word mask 0xf00 below");
+    uint32_t ra = ring_base | ((rd.in_rd << 8) & 0xf00u);
+    uint32_t wa = out_base | ((wr.vposw << 8) & 0xf00u);
+    uint32_t w2, e, nw, t, v;
+    uint64_t sv, sr;
+    asm volatile(
+        "Lstep_%=:\n"
+        "  v_alignbit_b32 %[w2], %[hi], %[lo], %[b]\n"
+        "  v_and_b32 %[t], 0x3ffc, %[w2]\n"
+        "  ds_read_b32 %[e], %[t]\n"
+        "  ds_read_b32 %[nw], %[ra]\n"
+        "  v_cmp_lt_u32 vcc, %[pos], %[end2]\n"
+        "  s_and_saveexec_b64 %[sv], vcc\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        "  v_and_b32 %[t], 0xe0, %[e]\n"
+        "  v_cmp_ne_u32 vcc, 0, %[t]\n"
+        "  s_cbranch_vccnz Lspecial_%=\n"
+        "  v_and_b32 %[t], 0xff, %[e]\n"
+        "  v_mov_b32 %[last], %[e]\n"
+        "  v_add_u32 %[pos], %[pos], %[t]\n"
+        "  v_add_u32 %[b], %[b], %[t]\n"
+        // append the literal bytes (entry bits 31:16) at byte sh / 8 of the accumulator
+        "  v_lshrrev_b32 %[v], 16, %[e]\n"
+        "  v_lshlrev_b32 %[t], %[sh], %[v]\n"
+        "  v_or_b32 %[acc], %[acc], %[t]\n"
+        "  ds_write_b32 %[wa], %[acc]\n"
+        "  v_sub_u32 %[t], 32, %[sh]\n"
+        "  v_lshrrev_b32 %[v], %[t], %[v]\n"  // bytes that did not fit (only used when the word fills up, sh > 0)
+        "  v_lshrrev_b32 %[t], 8, %[e]\n"
+        "  v_and_b32 %[t], 0xff, %[t]\n"
+        "  v_add_u32 %[sh], %[sh], %[t]\n"
+        "  v_cmp_lt_u32 vcc, 31, %[sh]\n"
+        "  v_and_b32 %[sh], 31, %[sh]\n"
+        "  s_mov_b64 %[sr], exec\n"
+        "  s_and_b64 exec, exec, vcc\n"  // lanes whose accumulator is full
+        "  v_mov_b32 %[acc], %[v]\n"
+        "  v_add_u32 %[t], 0x100, %[wa]\n"
+        "  v_and_b32 %[t], 0xf00, %[t]\n"
+        "  v_or_b32 %[wa], %[ob], %[t]\n"
+        "  v_add_u32 %[vposw], 1, %[vposw]\n"
+        "  s_mov_b64 exec, %[sr]\n"
+        "  v_cmp_lt_u32 vcc, 31, %[b]\n"
+        "  v_and_b32 %[b], 31, %[b]\n"
+        "  s_and_b64 exec, exec, vcc\n"  // lanes that crossed a dword of input
+        "  s_waitcnt lgkmcnt(0)\n"
+        "  v_mov_b32 %[lo], %[hi]\n"
+        "  v_mov_b32 %[hi], %[nw]\n"
+        "  v_add_u32 %[t], 0x100, %[ra]\n"
+        "  v_and_b32 %[t], 0xf00, %[t]\n"
+        "  v_or_b32 %[ra], %[rb], %[t]\n"
+        "  v_add_u32 %[ird], 1, %[ird]\n"
+        "  s_mov_b64 exec, %[sv]\n"
+        "  s_sub_u32 %[left], %[left], 1\n"
+        "  s_cmp_lg_u32 %[left], 0\n"
+        "  s_cbranch_scc1 Lstep_%=\n"
+        "  s_branch Ldone_%=\n"
+        "Lspecial_%=:\n"
+        "  s_mov_b64 exec, %[sv]\n"
+        "Ldone_%=:\n"
+        "  s_waitcnt lgkmcnt(0)\n"
+        : [left] "+s"(left), [pos] "+v"(pos), [last] "+v"(last_e), [lo] "+v"(rd.lo), [hi] "+v"(rd.hi),
+          [b] "+v"(rd.boff), [ra] "+v"(ra), [ird] "+v"(rd.in_rd), [acc] "+v"(wr.acc), [sh] "+v"(wr.sh),
+          [wa] "+v"(wa), [vposw] "+v"(wr.vposw), [w2] "=&v"(w2), [e] "=&v"(e), [nw] "=&v"(nw), [t] "=&v"(t),
+          [v] "=&v"(v), [sv] "=&s"(sv), [sr] "=&s"(sr)
+        : [end2] "v"(end2), [rb] "v"(ring_base), [ob] "v"(out_base)
+        : "vcc", "scc", "memory");
+    return left;
+}
+
 // The long loop of pass 1: from s.pos to `stop_at`, counting every byte.
 // Outer loop = one global-memory event, inner loop = kSegSteps look-ups that touch neither the
 // in-flight load registers nor global memory, so the compiler keeps waits and copies out of it.
@@ -344,41 +490,39 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
                                                    uint32_t stop_at, SegScan& s) {
     uint32_t lim = (active && s.stop == 0) ? stop_at : 0u;
     uint32_t iter = 0;
+    const uint32_t ring_base = lds_offset(rd.ring) + 4 * rd.lane_off;
     if (s.pos < lim) rd.refill_now();
     while (__any(s.pos < lim)) {
         rd.events(s.pos < lim);
-#pragma unroll 1
-        for (int k = 0; k < kSegSteps; k++) {
+        uint32_t gsum = 0;  // sum of the literal entries of this group: byte 1 = 8 x bytes (<= 8 x 16)
+        uint32_t left = kSegSteps;
+        while (left) {
+            left = seg_count_group(left, lim, ring_base, rd, s.pos, gsum, s.last_e);
+            if (left == 0) break;
+            // general step (selects only): some running lane looks at a run / end-of-block / impossible entry
+            left--;
             iter++;
             const uint32_t win = rd.window();
             const uint32_t e = lit[win & (kLitSize - 1)];
             const uint32_t nw = rd.peek();
-            const uint64_t run_m = __ballot(s.pos < lim), spec_m = __ballot((e & SE_SPECIAL) != 0);
-            if ((run_m & spec_m) == 0) {
-                if (s.pos < lim) {  // literals only: byte 0 = bits, byte 1 = 8 x bytes
-                    s.count8 += (e >> 8) & 0xFF;
-                    s.last_e = e;
-                    s.pos += e & 0xFF;
-                    rd.advance(e & 0xFF, nw);
-                }
-            } else {
-                const bool running = s.pos < lim;
-                const uint32_t used = seg_used(e);
-                const bool is_run = (e & SE_RUN) != 0;
-                const SegRun r = seg_run(e, win);
-                const bool fault = (e & SE_BAD) != 0 || (is_run && r.bad_dist) || s.pos + used > limit;
-                const bool step = running && !fault && (e & SE_EOB) == 0;
-                const bool halt = running && !step;
-                s.stop = halt ? (fault ? 2u : 1u) : s.stop;
-                s.eob_bits = halt ? used : s.eob_bits;
-                lim = halt ? 0u : lim;
-                s.count8 += step ? (is_run ? 8 * r.length : seg_n8(e)) : 0u;
-                s.last_e = (step && seg_n8(e) != 0) ? e : s.last_e;
-                const uint32_t adv = step ? used : 0u;
-                s.pos += adv;
-                rd.advance(adv, nw);
-            }
+            const bool running = s.pos < lim;
+            const uint32_t used = seg_used(e);
+            const bool is_run = (e & SE_RUN) != 0;
+            const SegRun r = seg_run(e, win);
+            const bool fault = (e & SE_BAD) != 0 || (is_run && r.bad_dist) || s.pos + used > limit;
+            const bool step = running && !fault && (e & SE_EOB) == 0;
+            const bool halt = running && !step;
+            s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+            s.eob_bits = halt ? used : s.eob_bits;
+            lim = halt ? 0u : lim;
+            s.count8 += step ? (is_run ? 8 * r.length : seg_n8(e)) : 0u;
+            s.last_e = (step && seg_n8(e) != 0) ? e : s.last_e;
+            const uint32_t adv = step ? used : 0u;
+            s.pos += adv;
+            rd.advance(adv, nw);
         }
+        s.count8 += (gsum >> 8) & 0xFF;
+        iter += kSegSteps;
         // the fast path checks neither of these per step; both are monotone within a group
         const bool over = active && s.stop == 0 && (s.pos > limit || rd.starved());
         s.stop = over ? 2u : s.stop;
@@ -422,6 +566,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         }
         ours = !__any(mismatch);
     }
+    ours = ours && lds_offset(L.lit) == 0;  // the hand-scheduled loops address the table from LDS offset 0
     if (!ours) {
         if (lane == 0) seg_leave_pending(a, sid);
         return;
@@ -666,6 +811,8 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     SEGTIME(4);
     if (live) rd.start(in, seg_bit0 + pos);
     uint32_t iter = 0;
+    const uint32_t ring_base = lds_offset(L.in_ring) + 4 * lane_off;
+    const uint32_t out_base = lds_offset(L.out_ring) + 4 * lane_off;
     // A lane runs while pos < end2 or a run is being filled.
     // Outer loop = drain + input event; inner loop = kSegSteps steps (<= 4 B each).
     while (__any(pos < end2 || fill != 0)) {
@@ -674,32 +821,23 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             if (fill >= kSegBulkFill) bulk_fill(seg_lastlit(last_e));
         }
         rd.events(pos < end2 || fill != 0);
-#pragma unroll 1
-        for (int k = 0; k < kSegSteps; k++) {
-            iter++;
-            const uint32_t win = rd.window();
-            const uint32_t e = lit[win & (kLitSize - 1)];
-            const uint32_t nw = rd.peek();
-            const uint64_t run_m = __ballot(pos < end2), spec_m = __ballot((e & SE_SPECIAL) != 0);
-            const uint64_t fill_m = __ballot(fill != 0);
-            if (((run_m & spec_m) | fill_m) == 0) {
-                if (pos < end2) {  // literals only: append 1-2 bytes
-                    pos += e & 0xFF;
-                    rd.advance(e & 0xFF, nw);
-                    last_e = e;
-                    const uint64_t t = (uint64_t)(e >> 16) << sh;
-                    acc |= (uint32_t)t;
-                    // the ring slot at vposw is always free: the (possibly partial) accumulator is
-                    // written there every time and only counts once it is full
-                    oring[seg_slot(lane_off, vposw)] = acc;
-                    const uint32_t tot = sh + ((e >> 8) & 0xFF);
-                    const bool full = tot >= 32;
-                    acc = full ? (uint32_t)(t >> 32) : acc;
-                    vposw += full ? 1u : 0u;
-                    sh = tot & 31;
-                }
-            } else {
+        uint32_t left = kSegSteps;
+        iter += kSegSteps;
+        while (left) {
+            if (!__any(fill != 0)) {  // nobody is filling a run: literal steps until a special entry turns up
+                SegWriter wr{acc, sh, vposw};
+                left = seg_write_group(left, end2, ring_base, out_base, rd, wr, pos, last_e);
+                acc = wr.acc;
+                sh = wr.sh;
+                vposw = wr.vposw;
+                if (left == 0) break;
+            }
+            left--;
+            {
                 // general step (selects only): a token of any kind, or 4 bytes of a run in progress
+                const uint32_t win = rd.window();
+                const uint32_t e = lit[win & (kLitSize - 1)];
+                const uint32_t nw = rd.peek();
                 const bool filling = fill != 0;
                 const bool dec = !filling && pos < end2;  // this lane decodes a token now
                 const bool is_run = (e & SE_RUN) != 0;
@@ -720,6 +858,8 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
                 end2 = bad_now ? 0u : end2;
                 const uint64_t t = (uint64_t)v << sh;
                 acc |= (uint32_t)t;
+                // the ring slot at vposw is always free: the (possibly partial) accumulator is
+                // written there every time and only counts once it is full
                 oring[seg_slot(lane_off, vposw)] = acc;
                 const uint32_t tot = sh + n8;
                 const bool full = tot >= 32;
