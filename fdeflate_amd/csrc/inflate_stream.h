@@ -268,8 +268,17 @@ struct Inflater {
         int64_t ring_lo = (int64_t)ring_top - kOutRing;
         bool need_global = (int64_t)at - (int64_t)d < ring_lo;
         if (need_global) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our own flush stores
+        // n and d are uniform: the (slow) remainder is only computed for overlapping copies
+        const bool overlap = d < n;
+        const float inv_d = overlap ? 1.0f / (float)d : 0.0f;
         for (uint32_t k = lane; k < n; k += kWave) {
-            uint32_t r = (d >= n) ? k : (k % d);
+            uint32_t r = k;
+            if (overlap) {  // k % d for k < 258 (exact: quotient estimate off by at most one)
+                uint32_t q = (uint32_t)((float)k * inv_d);
+                r = k - q * d;
+                if ((int32_t)r < 0) r += d;
+                if (r >= d) r -= d;
+            }
             uint32_t src = at - d + r;
             uint32_t b;
             if ((int64_t)src >= ring_lo) {
@@ -825,45 +834,75 @@ struct Inflater {
         TPHASE(13);
         GSTAT(15, nmatch);
         // ---- matches ----
-        // Short matches whose source lies wholly in front of the ring window read final bytes from
-        // global memory: they depend on nothing in this tile, so up to 64 of them are copied at once
-        // (one lane each) instead of one global round trip per match.
+        // A short match whose source ends in front of this tile's output depends on nothing in the
+        // tile (its source is final: in the ring, or -- older than the ring window -- in global
+        // memory), so up to 64 of them are copied at once, one lane each, instead of one after the
+        // other.  What is left (long matches, sources inside the tile) is replayed in order below.
         {
             const uint32_t ring_top = opos + total;
             const int64_t ring_lo = (int64_t)ring_top - kOutRing;
+#ifdef FDH_NO_PHASE_A
+            for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                const bool mine = j < nmatch;
+                const uint32_t m0 = mine ? io.mlist[2 * j] : 0u, dist = mine ? io.mlist[2 * j + 1] : 1u;
+                if (__any(mine && dist > opos + (m0 & 0xFFFF))) return ST_DISTANCE_TOO_FAR_BACK;
+            }
+            (void)ring_lo;
+#else
             for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
                 const uint32_t j = j0 + (uint32_t)lane;
                 const bool mine = j < nmatch;
                 const uint32_t m0 = mine ? io.mlist[2 * j] : 0u, dist = mine ? io.mlist[2 * j + 1] : 1u;
                 const uint32_t at = opos + (m0 & 0xFFFF), length = m0 >> 16;
                 if (__any(mine && dist > at)) return ST_DISTANCE_TOO_FAR_BACK;  // src/decompress.rs:782
-                const bool far = mine && length <= 16 && (int64_t)at - (int64_t)dist + (int64_t)length <= ring_lo;
+                const int64_t src_lo = (int64_t)at - (int64_t)dist, src_hi = src_lo + (int64_t)length;
+                const bool indep = mine && length <= 16 && src_hi <= (int64_t)opos;  // implies dist >= length
+                const bool far = indep && src_hi <= ring_lo;     // wholly in global memory (< flushed)
+                const bool near = indep && src_lo >= ring_lo;    // wholly in the ring
+                uint32_t b[16];
                 if (__any(far)) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our own flush stores
-                    uint32_t b[16];
-                    const uint8_t* src = out_al + gmis + (at - dist);  // dist >= length here
+                    // every lane issues all 16 loads back to back (idle ones re-read the slot's first
+                    // byte), so the batch costs one round trip, not one per byte
+                    const uint8_t* src = out_al + gmis + (far ? src_lo : 0);
 #pragma unroll
                     for (uint32_t k = 0; k < 16; k++) {
-                        b[k] = 0;
                         // L1-bypassing load: the line may have been cached before our later stores
-                        if (far && k < length) b[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        b[k] = __hip_atomic_load(src + ((far && k < length) ? k : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                }
+                if (near) {
 #pragma unroll
                     for (uint32_t k = 0; k < 16; k++) {
-                        if (far && k < length) io.out_ring[(at + k + gmis) & kOutMask] = (uint8_t)b[k];
+                        if (k < length) b[k] = io.out_ring[((uint32_t)src_lo + k + gmis) & kOutMask];
                     }
-                    if (far) io.mlist[2 * j] = m0 & 0xFFFF;  // length 0: done
+                }
+                if (far || near) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) {
+                        if (k < length) io.out_ring[(at + k + gmis) & kOutMask] = (uint8_t)b[k];
+                    }
+                    io.mlist[2 * j] = m0 & 0xFFFF;  // length 0: done
                 }
             }
+#endif
             wave_sync();
         }
+        TPHASE(7);
         // ---- replay the other matches in stream order (sources are final by then) ----
-        for (uint32_t j = 0; j < nmatch; j++) {
-            uint32_t m0 = uni(io.mlist[2 * j]), dist = uni(io.mlist[2 * j + 1]);
-            uint32_t at = opos + (m0 & 0xFFFF), length = m0 >> 16;
-            if (length == 0) continue;
-            copy_bytes(at, length, dist, opos + total);
-            wave_sync();
+        // descriptors travel in registers (lane j of a batch holds match j0 + j), not through LDS
+        for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
+            const uint32_t jj = j0 + (uint32_t)lane;
+            const uint32_t m0v = jj < nmatch ? io.mlist[2 * jj] : 0u, distv = jj < nmatch ? io.mlist[2 * jj + 1] : 1u;
+            const uint32_t nb = min(nmatch - j0, (uint32_t)kWave);
+            for (uint32_t j = 0; j < nb; j++) {
+                const uint32_t m0 = __builtin_amdgcn_readlane(m0v, j), dist = __builtin_amdgcn_readlane(distv, j);
+                const uint32_t at = opos + (m0 & 0xFFFF), length = m0 >> 16;
+                if (length == 0) continue;
+                copy_bytes(at, length, dist, opos + total);
+                wave_sync();
+            }
         }
         TPHASE(14);
 #ifdef FDH_DEBUG_TILES_TRACE
@@ -935,9 +974,8 @@ struct Inflater {
 #endif
             uint32_t rc = serial_token();
 #ifdef FDH_DEBUG_TILES
-            GSTAT(3, 1);
-            GSTAT(4, clock64() - t1);
-            GSTAT(7, consumed_bits() - c0);
+            (void)t1;
+            (void)c0;
 #endif
             if (rc != RC_OK) return rc;
             if (serial_credit) serial_credit--;
