@@ -24,8 +24,8 @@
 //
 // Input is read per lane through a small LDS ring that is topped up by 16-B global loads at
 // wavefront-uniform "events" (two events ahead), so the hot loop never waits on memory.
-// Anything unusual -- not canonical, too short, a bad / truncated token, a full slot, a
-// checksum mismatch -- leaves the stream PENDING for the exact wave-per-stream kernels.
+// Anything unusual -- not canonical, a bad / truncated token, a full slot, a checksum
+// mismatch -- leaves the stream PENDING for the exact wave-per-stream kernels.
 #pragma once
 #include "inflate_tables.h"
 
@@ -56,7 +56,7 @@ constexpr int kSegChunk = kSegInWords / 4; // dwords per global load of a lane (
 constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation
 constexpr int kSegSteps = kSegInWords / 2;  // table look-ups between two global-memory events
 constexpr uint32_t kSegNeed = (kSegSteps * 18 + 31) / 32;  // dwords a group of steps can consume (18 bits/token)
-constexpr uint32_t kSegMinBits = 4 * kSegWindow;  // shorter segments: not worth it -> PENDING
+constexpr uint32_t kSegMinBits = 4 * kSegWindow;  // aim: no segment shorter than this (fewer lanes are used instead)
 #ifndef FDH_BULK
 #define FDH_BULK 64
 #endif
@@ -551,7 +551,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint8_t* buf_hi = a.in + a.in_off[a.n];
     const uint64_t ilen = i1 - i0, ocap = o1 - o0;
     bool ours = ilen < (1ull << 28) && ocap < (1ull << 31) && (reinterpret_cast<uintptr_t>(op) & 15) == 0 &&
-                ilen * 8 >= a.canon_bits + 64ull * kSegMinBits;
+                ilen * 8 >= a.canon_bits + 44ull;  // room for an end-of-block symbol and the Adler-32
     const uint32_t in_bits = (uint32_t)(ilen * 8);
     const uint32_t cap = (uint32_t)ocap;
     // canonical prefix: lane k compares stream dword k
@@ -571,11 +571,13 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         if (lane == 0) seg_leave_pending(a, sid);
         return;
     }
-    // ---- segments: 64 equal bit ranges of the block data (the trailer bits ride along) ----
+    // ---- segments: equal bit ranges of the block data (the trailer bits ride along), one per lane;
+    //      short streams use fewer lanes so that a segment stays several windows long ----
     const uint32_t data_bits = in_bits - a.canon_bits;
-    const uint32_t seg = (data_bits + kWave - 1) / kWave;
+    const uint32_t nseg = min((uint32_t)kWave, max(1u, (data_bits + kSegMinBits - 1) / kSegMinBits));
+    const uint32_t seg = (data_bits + nseg - 1) / nseg;
     const uint32_t seg_bit0 = a.canon_bits + (uint32_t)lane * seg;  // first bit of this lane's segment
-    const bool in_range = seg_bit0 < in_bits;
+    const bool in_range = (uint32_t)lane < nseg && seg_bit0 < in_bits;
     const uint32_t limit = in_range ? in_bits - seg_bit0 : 0;       // tokens must end at or before this
 
     SegReader rd;
