@@ -550,7 +550,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     uint8_t* op = a.out + o0;
     const uint8_t* buf_hi = a.in + a.in_off[a.n];
     const uint64_t ilen = i1 - i0, ocap = o1 - o0;
-    bool ours = ilen < (1ull << 28) && ocap < (1ull << 31) && (reinterpret_cast<uintptr_t>(op) & 15) == 0 &&
+    bool ours = ilen < (1ull << 28) && ocap < (1ull << 31) &&
                 ilen * 8 >= a.canon_bits + 44ull;  // room for an end-of-block symbol and the Adler-32
     const uint32_t in_bits = (uint32_t)(ilen * 8);
     const uint32_t cap = (uint32_t)ocap;
@@ -719,8 +719,10 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     // except what pass 1 cannot know: a run with nothing before it.
     uint32_t end2 = live ? tail.pos : 0u;  // chain end (>= seg) or the end-of-block position; 0 = halted
     uint32_t pos = start;
-    const uint32_t pad = obase & 15;            // bytes in front of this lane's first byte in its 16-B line
-    uint8_t* const line0 = op + (obase - pad);  // 16-B aligned
+    // bytes in front of this lane's first byte in its 16-B line of global memory (the slot itself may
+    // start anywhere; the first and the last line of a lane are stored byte by byte)
+    const uint32_t pad = (uint32_t)(reinterpret_cast<uintptr_t>(op) + obase) & 15;
+    uint8_t* const line0 = op + obase - pad;    // 16-B aligned; may lie in front of the slot for lane 0
     uint32_t vposw = pad >> 2;                  // virtual position in dwords: words already in the ring
     uint32_t acc = 0, sh = 8 * (pad & 3);       // 4-byte accumulator holding sh / 8 bytes (the rest is zero)
     uint32_t vstored = 0;                       // virtual bytes stored to global (multiple of 16)

@@ -189,6 +189,44 @@ def test_segment_kernel_long_canonical_streams(harness):
     harness.assert_inflate_parity(names, blobs, caps, flags=128)
 
 
+def test_segment_kernel_alone_short_and_unaligned(harness):
+    """The segment-parallel kernel on its own (FDH_FLAG_FIRST_ONLY): canonical streams of every
+    small size, at odd slot alignments.  It may leave a stream PENDING, but whatever it reports as
+    Ok must be the reference's answer -- and it must take the plain cases."""
+    from fdeflate_amd import synth
+    r = np.random.default_rng(5)
+    raws = [b"", b"a", b"\x00", b"\x00" * 5, b"\x00" * 258, b"\x00" * 259, b"\x00" * 100000, b"ab" * 700]
+    for n in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 1000, 1023, 1024, 1025,
+                                   2047, 2048, 4095, 4096, 4097, 9000, 20000]:
+        raws.append(r.integers(0, 256, n, dtype=np.uint8).tobytes())
+        x = r.integers(0, 256, n, dtype=np.uint8)
+        x[r.random(n) < 0.7] = 0
+        raws.append(x.tobytes())
+    raws.append(synth.gen_stream_np(3, 4096).tobytes())
+    names, blobs, caps = [], [], []
+    for k, raw in enumerate(raws):
+        comp = ob.compress_ultra_fast(raw)
+        for c in (len(raw), len(raw) + 7, max(len(raw) - 1, 0)):
+            names.append("s%d@%d" % (k, c))
+            blobs.append(comp)
+            caps.append(c)
+        names.append("s%d_trunc" % k)
+        blobs.append(comp[:-3])
+        caps.append(len(raw))
+    st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=64)
+    rs, rl, ra, ro = harness.oracle_inflate(blobs, caps)
+    assert guards_ok, "the segment kernel wrote outside a slot"
+    taken = 0
+    for i, name in enumerate(names):
+        assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
+        if int(st[i]) == 0:
+            taken += 1
+            assert rs[i] == 0, (name, "reported Ok, reference says", ob.STATUS_NAMES[rs[i]])
+            assert int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
+    plain = sum(1 for i in range(len(names)) if rs[i] == 0)
+    assert taken >= 0.9 * plain, (taken, plain)
+
+
 def test_valid_streams_ignore_adler(harness):
     names, blobs, caps = [], [], []
     for name, comp, raw in streams.valid_streams():
