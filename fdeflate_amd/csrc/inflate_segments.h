@@ -766,7 +766,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             blocks = 0;
         }
     };
-    auto drain = [&]() __attribute__((always_inline)) {
+    auto drain_all = [&]() __attribute__((always_inline)) {  // every complete 16-B line
         while (__any(4 * vposw - vstored >= 16)) {
             if (4 * vposw - vstored >= 16) {
                 store_piece(vstored);
@@ -774,9 +774,33 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             }
         }
     };
+#ifndef FDH_SEG_DRAIN16
+    // Lines leave in 32-B aligned pairs (two adjacent 16-B stores back to back) so that whole
+    // 32-B sectors reach the L2 together; a lane whose first line is the upper half of a sector
+    // sends that one alone.  < 32 B stay behind, + <= 32 B per group of steps: fits the 64-B ring.
+    const bool odd_first = (reinterpret_cast<uintptr_t>(line0) & 16) != 0;
+    auto drain = [&]() __attribute__((always_inline)) {
+        for (;;) {
+            const uint32_t avail = 4 * vposw - vstored;
+            const bool single = odd_first && vstored == 0 && avail >= 16;
+            const bool pair = !single && avail >= 32;
+            if (!__any(single || pair)) break;
+            if (single || pair) {
+                store_piece(vstored);
+                vstored += 16;
+            }
+            if (pair) {
+                store_piece(vstored);
+                vstored += 16;
+            }
+        }
+    };
+#else
+    auto drain = drain_all;
+#endif
     // A long dist-1 run (src/decompress.rs:793-801 fills it with one byte): bring the lane to a
     // 16-B line boundary through the ring, then store whole lines of the byte directly; their
-    // Adler-32 contribution has a closed form.  Called with less than a line waiting in the ring.
+    // Adler-32 contribution has a closed form.
     auto bulk_fill = [&](uint32_t c) __attribute__((always_inline)) {
         const uint32_t c4 = c * 0x01010101u;
         // complete the accumulator, then whole words up to the line boundary
@@ -791,7 +815,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             vposw++;
             fill -= 4;
         }
-        if (4 * vposw != vstored) {  // exactly one line is waiting in the ring
+        while (4 * vposw != vstored) {  // the complete lines waiting in the ring
             store_piece(vstored);
             vstored += 16;
         }
@@ -883,7 +907,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     SEGDBG(4, iter);
     SEGDBG(7, total);
     // ---- tail of every lane: the last (partial) line ----
-    drain();
+    drain_all();
     if (live) {
         // the loose bytes go into the ring as a final word; zero the rest of that 16-B line
         oring[seg_slot(lane_off, vposw)] = acc;
