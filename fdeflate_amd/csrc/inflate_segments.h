@@ -206,8 +206,19 @@ struct SegReader {
     // Synchronous top-up (once, between the window walk and the long counting loop): commits what is
     // in flight, then loads until the ring is full.
     __device__ __forceinline__ void refill_now() {
+#ifndef FDH_SEG_SINGLELOAD
+        if (has_a) {  // a pair is in flight: take it if it fits, otherwise ask again below
+            if ((uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)(2 * kSegChunk)) {
+                put(pend_a);
+                put(pend_b);
+            } else {
+                gp -= 8 * kSegChunk;
+            }
+        }
+#else
         if (has_a) put(pend_a);
         if (has_b) put(pend_b);
+#endif
         has_a = has_b = false;
         while ((uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)kSegChunk) {
             put(seg_load(gp, buf_lo, buf_hi));
@@ -229,6 +240,24 @@ struct SegReader {
         hi = wrap ? nw : hi;
         in_rd += wrap ? 1u : 0u;
     }
+#ifndef FDH_SEG_SINGLELOAD
+    // Wavefront-uniform event, pair policy: two adjacent chunks (one 32-B sector of a 16-dword ring's
+    // lane) are requested together and committed together once the ring has room for both, so a
+    // 128-B line of input is visited 4 times instead of 8.  has_a == has_b at all times.
+    __device__ __forceinline__ void event(bool want_more) {
+        if (has_a && (uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)(2 * kSegChunk)) {
+            put(pend_a);
+            put(pend_b);
+            has_a = has_b = false;
+        }
+        if (want_more && !has_a) {
+            pend_a = seg_load(gp, buf_lo, buf_hi);
+            pend_b = seg_load(gp + 4 * kSegChunk, buf_lo, buf_hi);
+            gp += 8 * kSegChunk;
+            has_a = has_b = true;
+        }
+    }
+#else
     // Wavefront-uniform event: commit what was requested two events ago, request the next chunk.
     __device__ __forceinline__ void event(bool want_more) {
         if (has_a) put(pend_a);
@@ -241,6 +270,7 @@ struct SegReader {
             has_b = true;
         }
     }
+#endif
     // One event per kSegSteps steps keeps up with a chunk per group; a group can consume up to
     // kSegSteps * 18 bits = kSegNeed dwords, so denser stretches get extra (waiting) events.
     __device__ __forceinline__ void events(bool running) {
