@@ -227,6 +227,52 @@ def test_segment_kernel_alone_short_and_unaligned(harness):
     assert taken >= 0.9 * plain, (taken, plain)
 
 
+def test_segment_kernel_random_stress(harness):
+    """Many random canonical streams (sizes 0..200 KiB, zero density 0..100 %, long runs, exact /
+    loose / short slots, corrupted and truncated copies) against the oracle, through the full
+    pipeline and with the segment kernel's result taken alone."""
+    r = np.random.default_rng(2024)
+    names, blobs, caps = [], [], []
+    for k in range(400):
+        n = int(r.choice([r.integers(0, 300), r.integers(300, 5000), r.integers(5000, 70000), r.integers(70000, 200000)]))
+        dens = float(r.choice([0.0, 0.1, 0.5, 0.9, 0.99, 1.0]))
+        x = r.integers(0, 256, n, dtype=np.uint8)
+        if r.random() < 0.5:
+            x = (x % int(r.choice([2, 4, 17, 64]))).astype(np.uint8)
+        x[r.random(n) < dens] = 0
+        if n > 600 and r.random() < 0.5:
+            a = int(r.integers(0, n - 500))
+            x[a:a + int(r.integers(1, 500))] = int(r.integers(0, 256))  # a run of a non-zero byte is NOT a run token
+        raw = x.tobytes()
+        comp = ob.compress_ultra_fast(raw)
+        mode = k % 5
+        if mode == 0:
+            cap = n
+        elif mode == 1:
+            cap = n + int(r.integers(1, 100))
+        elif mode == 2:
+            cap = max(0, n - int(r.integers(1, 50)))
+        elif mode == 3:
+            cap = n
+            b = bytearray(comp)
+            b[int(r.integers(2, len(b)))] ^= 1 << int(r.integers(0, 8))
+            comp = bytes(b)
+        else:
+            cap = n
+            comp = comp[:int(r.integers(1, len(comp)))]
+        names.append("r%d_m%d_n%d" % (k, mode, n))
+        blobs.append(comp)
+        caps.append(cap)
+    harness.assert_inflate_parity(names, blobs, caps)
+    st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=64)
+    rs, rl, ra, ro = harness.oracle_inflate(blobs, caps)
+    assert guards_ok
+    for i, name in enumerate(names):
+        assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
+        if int(st[i]) == 0:
+            assert rs[i] == 0 and int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
+
+
 def test_valid_streams_ignore_adler(harness):
     names, blobs, caps = [], [], []
     for name, comp, raw in streams.valid_streams():
