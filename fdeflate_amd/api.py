@@ -30,6 +30,9 @@ FLAG_GENERAL_ONLY = 4
 FLAG_NO_RECHECK = 8
 FLAG_FORCE_LANES = 16
 FLAG_NO_LANES = 32
+FLAG_FIRST_ONLY = 64
+FLAG_NO_SEGMENTS = 128
+FLAG_SPANS = 256
 
 
 class DecompressionError(Exception):

@@ -65,7 +65,9 @@ struct InflateBatchArgs {
     uint32_t flags;
     uint32_t only_pending;
     const uint32_t* list;  // nullable: compacted ids of the PENDING streams ([0] = count, [4..] = ids)
+    uint32_t* span_pool;   // nullable: kSpanSlots busy flags, then kSpanSlots match lists (span decoder scratch)
 };
+constexpr uint32_t kSpanSlots = 2048;  // > workgroups of the general kernel resident on one device (256 CUs x 5)
 
 __device__ __forceinline__ StreamArgs stream_args(const InflateBatchArgs& a, uint64_t sid) {
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
@@ -113,8 +115,23 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
     Inflater inf(lds.tables, lds.io, &lds.hs, lane);
     StreamResult r;
     if (tiles) {
+        // the span decoder lists matches in global scratch: take one of the pool's slots
+        uint32_t slot = kSpanSlots;
+        if (a.span_pool && (a.flags & 0x100u) && s.in_len >= 4096) {
+            if (lane == 0) {
+                slot = (uint32_t)(sid % kSpanSlots);
+                while (atomicCAS(&a.span_pool[slot], 0u, 1u) != 0u) slot = (slot + 1) % kSpanSlots;
+            }
+            slot = uni(slot);
+            inf.span_list = a.span_pool + kSpanSlots + (size_t)slot * (2 * kSpanMaxMatches);
+        }
         inf.init(s);
         r = inf.run<true, false>();
+        if (slot < kSpanSlots) {
+            __threadfence();
+            if (lane == 0) atomicExch(&a.span_pool[slot], 0u);
+        }
+        inf.span_list = nullptr;
         if (needs_serial_recheck(r, a.flags)) tiles = false;
     }
     if (!tiles) {
@@ -325,6 +342,7 @@ extern "C" int fdh_debug_read(uint32_t* host, uint32_t nwords, int reset) {
 // device address of g_canon, looked up once per device by fdh_launch_canon_build (the lookup
 // synchronises, so it must stay off the launch path)
 static fdh::CanonTables* g_canon_dev[64] = {};
+static uint32_t* g_span_pool[64] = {};  // per device: scratch of the span decoder (never freed)
 
 extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status) {
     hipLaunchKernelGGL(fdh::canon_build_kernel, dim3(1), dim3(fdh::kWave), 0, stream);
@@ -346,7 +364,24 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr};
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr};
+    if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
+        int ordinal = 0;
+        if (hipGetDevice(&ordinal) == hipSuccess && ordinal >= 0 && ordinal < 64) {
+            if (!g_span_pool[ordinal]) {
+                const size_t bytes = ((size_t)fdh::kSpanSlots + (size_t)fdh::kSpanSlots * 2 * fdh::kSpanMaxMatches) * sizeof(uint32_t);
+                uint32_t* p = nullptr;
+                if (hipMalloc(reinterpret_cast<void**>(&p), bytes) == hipSuccess) {
+                    if (hipMemset(p, 0, fdh::kSpanSlots * sizeof(uint32_t)) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+                        g_span_pool[ordinal] = p;
+                    else (void)hipFree(p);
+                } else {
+                    (void)hipGetLastError();  // no scratch: the general kernel runs without spans
+                }
+            }
+            a.span_pool = g_span_pool[ordinal];
+        }
+    }
     if (flags & 6u) {  // FDH_FLAG_SERIAL_ONLY (2) / debug: general kernel only, tiles allowed (4)
         hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
         return (int)hipGetLastError();

@@ -24,6 +24,7 @@
 // unread stream bits) is RC_STUCK here with the same threshold on `left`.
 #pragma once
 #include "inflate_tables.h"
+#include "inflate_segments.h"  // SegReader (per-lane bit reader over an LDS ring)
 
 namespace fdh {
 
@@ -34,6 +35,9 @@ constexpr int kOutMask = kOutRing - 1;
 constexpr int kFlushSlack = 64;
 constexpr int kMaxMatches = 256;            // match tokens replayed per tile
 constexpr int kTileBits = 64;               // stream bits owned by one lane of a tile
+constexpr uint32_t kSpanSegBits = 1024;     // stream bits owned by one lane of a span
+constexpr uint32_t kSpanMinSeg = 512;       // shorter segments: not worth a span, tiles take over
+constexpr uint32_t kSpanMaxMatches = 8192;  // match tokens per span (scratch list capacity)
 
 // Decode tables of the current block.
 struct __attribute__((aligned(16))) TableSet {
@@ -169,9 +173,11 @@ struct Inflater {
     bool last_block;
     uint32_t flags;
     uint32_t serial_credit;  // tokens to decode serially before the next tile attempt
+    uint32_t* span_list;     // scratch of this workgroup: kSpanMaxMatches x {at, length | dist << 16}; null: no spans
+    uint32_t span_credit;    // tiles to run before the next span attempt (after a span that did not pay)
 
     __device__ __forceinline__ Inflater(TableSet& t, WaveIo& w, HeaderScratch* h, int ln)
-        : T(t), io(w), hs(h), lane(ln) {}
+        : T(t), io(w), hs(h), lane(ln), span_list(nullptr) {}
 
     // ------------------------------------------------------------------ input window
     __device__ __forceinline__ void load_chunk(uint32_t c) {
@@ -372,6 +378,7 @@ struct Inflater {
         eof_code = eof_mask = eof_bits = 0;
         flags = a.flags;
         serial_credit = 0;
+        span_credit = 0;
         seek(0);
     }
 
@@ -661,7 +668,11 @@ struct Inflater {
 
 #ifdef FDH_DEBUG_TILES
         long long tq = clock64();
+#ifdef FDH_DEBUG_SPAN
+#define TPHASE(k) do { (void)tq; } while (0)
+#else
 #define TPHASE(k) do { long long tn = clock64(); GSTAT(k, tn - tq); tq = tn; } while (0)
+#endif
 #else
 #define TPHASE(k) do { } while (0)
 #endif
@@ -947,12 +958,512 @@ struct Inflater {
         return rc;
     }
 
+    // ------------------------------------------------------------------ span decoder
+    // Segment-parallel decode of the next 64 x `seg` stream bits of the current block -- the scheme
+    // of inflate_segments.h with this block's own tables: every lane decodes its bit range
+    // sequentially (pass 1 from a guessed start: walk a 256-bit window, then count bytes and
+    // matches; check: the real start from the left neighbour must land on the same boundary;
+    // prefix sums; pass 2 writes the literals to the output slot and lists the matches, leaving
+    // zeroed holes), then the matches are resolved from the list, 64 at a time, against a
+    // "resolved up to" frontier; the Adler-32 is taken over the finished bytes.  The staging rings
+    // of the wavefront are reused as per-lane rings; the input window and the output ring are
+    // re-established afterwards.  Like a tile, a span ends in front of anything it cannot prove
+    // harmless.  `progress` = stream bits consumed.
+    struct SpanTok {
+        uint32_t kind;    // 0 literal(s), 1 match, 2 end-of-block, 3 bad
+        uint32_t bits_a;  // literal entry / end-of-block: all its bits; match: length code + extra bits
+        uint32_t bits_b;  // match: distance code + extra bits
+        uint32_t n, lits, n1;  // literals: count, bytes, bits of the first one alone
+        uint32_t length, dist;
+    };
+    __device__ __forceinline__ SpanTok span_token(uint64_t w) {
+        SpanTok t;
+        t.bits_b = t.n = t.lits = t.n1 = t.length = t.dist = 0;
+        uint32_t e = T.lit[(uint32_t)w & (kLitSize - 1)];
+        if (((e >> 4) & 15) == K_LONG) {
+            uint32_t sym, len;
+            if (long_walk(T.lit_cb, T.lit_sorted, (uint32_t)w, kLitBits + 1, sym, len)) e = LitlenTraits::entry(sym, len);
+        }
+        const uint32_t nb = e & 15, k = (e >> 4) & 15;
+        t.bits_a = nb;
+        t.kind = 3;
+        if (k == K_LIT1) {
+            t.kind = 0;
+            t.n = 1;
+            t.lits = (e >> 8) & 0xFF;
+            t.n1 = nb;
+        } else if (k == K_LIT2) {
+            t.kind = 0;
+            t.n = 2;
+            t.lits = (e >> 8) & 0xFFFF;
+            t.n1 = e >> 24;
+        } else if (k == K_LEN) {
+            const uint32_t lex = (e >> 8) & 31;
+            t.length = (e >> 16) + ((uint32_t)(w >> nb) & ((1u << lex) - 1));
+            t.bits_a = nb + lex;
+            const uint32_t v = (uint32_t)(w >> t.bits_a);
+            uint32_t de = T.dist[v & (kDistSize - 1)];
+            if (((de >> 4) & 15) == D_LONG) {
+                uint32_t sym, len;
+                if (long_walk(T.dist_cb, T.dist_sorted, v, kDistBits + 1, sym, len)) de = DistTraits::entry(sym, len);
+            }
+            if (((de >> 4) & 15) == D_DIST) {
+                const uint32_t dcb = de & 15, dex = (de >> 8) & 15;
+                t.dist = (de >> 16) + ((v >> dcb) & ((1u << dex) - 1));
+                t.bits_b = dcb + dex;
+                t.kind = 1;
+            }
+        } else if (k == K_EOB) {
+            t.kind = 2;
+        }
+        return t;
+    }
+    // 62 stream bits at the reader's position (the reader sits two bits in front of the token)
+    __device__ __forceinline__ uint64_t span_window(const SegReader& rd, uint32_t nw) {
+        const uint32_t w_lo = __builtin_amdgcn_alignbit(rd.hi, rd.lo, rd.boff);
+        const uint32_t w_hi = __builtin_amdgcn_alignbit(nw, rd.hi, rd.boff);
+        return (((uint64_t)w_hi << 32) | w_lo) >> 2;
+    }
+    __device__ __forceinline__ void span_events(SegReader& rd, bool running) {
+        rd.event(running);
+        for (int x = 0; x < 2 && __any(running && rd.level() < 8); x++) rd.event(running);  // tokens up to 48 bits
+    }
+    struct SpanScan {
+        uint32_t pos, count, nmatch, stop, stop_bits;
+    };
+    // GUESS + WINDOW: walk the synchronisation window without counting, sliding over impossible
+    // tokens.  WINDOW alone: the real chain through the window, counted, literal pairs split close
+    // to the window's end.  Neither: count to `stop_at`.
+    template <bool GUESS, bool WINDOW>
+    __device__ __forceinline__ void span_scan(SegReader& rd, uint32_t limit, bool active, uint32_t stop_at, SpanScan& s) {
+        bool running = active && s.stop == 0 && s.pos < stop_at;
+        if (!WINDOW && running) rd.refill_now();
+        while (__any(running)) {
+            span_events(rd, running);
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                const uint32_t nw = rd.peek();
+                const SpanTok t = span_token(span_window(rd, nw));
+                uint32_t kind = t.kind, bits_a = t.bits_a, bits_b = t.bits_b, n = t.n;
+                if (WINDOW) {
+                    const bool single = kind == 0 && n == 2 && s.pos + 24 >= (uint32_t)kSegWindow;
+                    bits_a = single ? t.n1 : bits_a;
+                    n = single ? 1u : n;
+                }
+                if (GUESS) {
+                    const bool slide = kind >= 2 && s.pos + 1 <= limit;
+                    bits_a = slide ? 1u : bits_a;
+                    bits_b = slide ? 0u : bits_b;
+                    n = slide ? 0u : n;
+                    kind = slide ? 0u : kind;
+                }
+                const uint32_t bits = bits_a + bits_b;
+                const bool fault = kind == 3 || s.pos + bits > limit || rd.starved();
+                const bool step = running && !fault && kind != 2;
+                const bool halt = running && !step;
+                s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+                s.stop_bits = halt ? bits_a : s.stop_bits;
+                if (!GUESS) {
+                    s.count += step ? (kind == 1 ? t.length : n) : 0u;
+                    s.nmatch += (step && kind == 1) ? 1u : 0u;
+                }
+                rd.advance(step ? bits_a : 0u, nw);
+                if (__any(step && kind == 1)) {
+                    const uint32_t nw2 = rd.peek();
+                    rd.advance((step && kind == 1) ? bits_b : 0u, nw2);
+                }
+                s.pos += step ? bits : 0u;
+                running = step && s.pos < stop_at;
+            }
+        }
+    }
+    // The last kOutRing bytes of output back into the output ring (history of later matches), by
+    // whole 16-B lines of the slot's address space; what lies outside [.., opos) is never read.
+    // Everything up to opos must be in the slot (flushed == opos).
+    __device__ __forceinline__ void span_reload_out_ring() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        const uint32_t lo_p = opos > (uint32_t)(kOutRing - 16) ? opos - (kOutRing - 16) : 0;
+        for (uint32_t lq = ((lo_p + gmis) & ~15u) + (uint32_t)lane * 16; lq < opos + gmis; lq += kWave * 16) {
+            const uint32_t* lp = reinterpret_cast<const uint32_t*>(out_al + lq);
+            uint4 v;
+            v.x = __hip_atomic_load(lp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.y = __hip_atomic_load(lp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.z = __hip_atomic_load(lp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.w = __hip_atomic_load(lp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<uint4*>(&io.out_ring[lq & kOutMask]) = v;
+        }
+        wave_sync();
+    }
+    __device__ __forceinline__ uint32_t span_step(uint32_t& progress) {
+        progress = 0;
+        const uint64_t P64 = consumed_bits();
+        const uint64_t total_bits64 = (win_bytes - mis) * 8;
+        if (total_bits64 >= (1ull << 31) || cap >= (1u << 31) || P64 < 8) {
+            span_credit = ~0u;
+            return RC_OK;
+        }
+        const uint32_t P = (uint32_t)P64, in_bits = (uint32_t)total_bits64;
+        const uint32_t seg = min(kSpanSegBits, (in_bits - P + kWave - 1) / kWave);
+        if (seg < kSpanMinSeg) {  // the tail of a stream: tiles
+            span_credit = ~0u;
+            return RC_OK;
+        }
+        flush(true);  // everything decoded so far is in the slot; the staging rings are free now
+        const uint32_t seg_bit0 = P + (uint32_t)lane * seg;
+        const bool in_range = seg_bit0 < in_bits;
+        const uint32_t limit = in_range ? in_bits - seg_bit0 : 0;
+
+        SegReader rd;
+        rd.ring = reinterpret_cast<uint32_t*>(&io);
+        rd.lane_off = (uint32_t)lane;
+        rd.buf_lo = buf_lo;
+        rd.buf_hi = buf_hi;
+        rd.gp = in;
+        rd.in_wr = rd.in_rd = 0;
+        rd.lo = rd.hi = rd.boff = 0;
+        for (int k = 0; k < kSegChunk; k++) rd.pend_a.w[k] = rd.pend_b.w[k] = 0;
+        rd.has_a = rd.has_b = false;
+        uint32_t* const oring = reinterpret_cast<uint32_t*>(&io) + kSegInWords * kWave;
+        static_assert(sizeof(WaveIo) >= (kSegInWords + kSegOutWords) * kWave * 4, "span rings overlay the staging rings");
+        loaded = 0;  // the input window is gone (seek() below reloads it)
+
+#ifdef FDH_DEBUG_SPAN
+        long long sq = clock64();
+#define SPHASE(k) do { long long tn = clock64(); GSTAT(k, tn - sq); sq = tn; } while (0)
+#else
+#define SPHASE(k) do { } while (0)
+#endif
+        // ---- pass 1 ----
+        SpanScan tail;
+        tail.pos = tail.count = tail.nmatch = tail.stop = tail.stop_bits = 0;
+        if (in_range) rd.start(in, seg_bit0);
+        span_scan<true, true>(rd, limit, in_range, (uint32_t)kSegWindow, tail);
+        uint32_t x0 = tail.stop == 0 ? tail.pos : 0;
+        span_scan<false, false>(rd, limit, in_range, seg, tail);
+        SPHASE(10);
+        // ---- check ----
+        SpanScan head;
+        head.pos = head.count = head.nmatch = head.stop = head.stop_bits = 0;
+        uint32_t start = 0, cur_start = ~0u;
+        bool giveup = false;
+        for (int round = 0; round < 6; round++) {
+            const uint32_t prev_end = __shfl_up(tail.pos, 1, kWave);
+            const uint32_t prev_stop = __shfl_up(tail.stop, 1, kWave);
+            start = lane == 0 ? 0 : prev_end - seg;
+            const bool have_in = lane == 0 || (prev_stop == 0 && prev_end >= seg);
+            const bool need = in_range && have_in && start != cur_start;
+            if (!__any(need)) break;
+            if (round == 5) giveup = true;
+            if (need) {
+                head.pos = start;
+                head.count = head.nmatch = head.stop = head.stop_bits = 0;
+                rd.start(in, seg_bit0 + start);
+            }
+            span_scan<false, true>(rd, limit, need, (uint32_t)kSegWindow, head);
+            const bool stopped_in_head = need && head.stop != 0;
+            const bool redo = need && head.stop == 0 && (head.pos != x0 || x0 == 0);
+            if (stopped_in_head) {
+                tail = head;
+                tail.count = tail.nmatch = 0;
+                x0 = head.pos;
+            }
+            if (__any(redo)) {
+                if (redo) {
+                    tail.pos = head.pos;
+                    tail.count = tail.nmatch = tail.stop = tail.stop_bits = 0;
+                    x0 = head.pos;
+                }
+                span_scan<false, false>(rd, limit, redo, seg, tail);
+            }
+            if (need) cur_start = start;
+        }
+        const bool verified = in_range && cur_start == start;
+        const uint64_t stop_mask = __ballot(verified && tail.stop != 0);
+        const uint64_t unver_mask = __ballot(!verified);
+        const int stop_lane = stop_mask ? __ffsll((unsigned long long)stop_mask) - 1 : kWave;
+        const int first_unver = unver_mask ? __ffsll((unsigned long long)unver_mask) - 1 : kWave;
+        // lanes [0, nlive) hold verified chains; the last of them may end at a stop
+        const int nlive = min(first_unver, stop_lane + 1);
+        if (giveup || nlive == 0) {
+            span_credit = 16;
+            span_reload_out_ring();
+            seek(P64);
+            return RC_OK;
+        }
+        const bool live = lane < nlive;
+        const uint32_t count = live ? head.count + tail.count : 0;
+        const uint32_t mcount = live ? head.nmatch + tail.nmatch : 0;
+        unsigned long long incl = (unsigned long long)count | ((unsigned long long)mcount << 40);
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            unsigned long long y = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += y;
+        }
+        const unsigned long long tot = __shfl(incl, kWave - 1, kWave);
+        const unsigned long long total64 = tot & ((1ull << 40) - 1);
+        const uint32_t nmatch = (uint32_t)(tot >> 40);
+        if (total64 > (unsigned long long)(cap - opos) || nmatch > kSpanMaxMatches) {  // tiles cope with these
+            span_credit = 64;
+            span_reload_out_ring();
+            seek(P64);
+            return RC_OK;
+        }
+        const uint32_t total = (uint32_t)total64;
+        const uint32_t obase = (uint32_t)(incl & ((1ull << 40) - 1)) - count;
+        uint32_t mi = (uint32_t)(incl >> 40) - mcount;
+
+        SPHASE(11);
+        // ---- pass 2: literals to the slot, matches to the list (their bytes are zero for now) ----
+        {
+            const uint32_t my_end = live ? tail.pos : 0u;
+            uint32_t pos = start;
+            uint32_t guard = 0;
+            uint8_t* const op = out_al + gmis + opos;
+            const uint32_t pad = (uint32_t)(reinterpret_cast<uintptr_t>(op) + obase) & 15;
+            uint8_t* const line0 = op + obase - pad;
+            uint32_t vposw = pad >> 2, acc = 0, sh = 8 * (pad & 3), vstored = 0, fill = 0, produced = 0;
+            const uint32_t vend = pad + count;
+            oring[seg_slot((uint32_t)lane, 0)] = 0;
+            oring[seg_slot((uint32_t)lane, 1)] = 0;
+            oring[seg_slot((uint32_t)lane, 2)] = 0;
+            auto store_piece = [&](uint32_t vs) __attribute__((always_inline)) {
+                const uint32_t w = vs >> 2;
+                uint4 q;
+                q.x = oring[seg_slot((uint32_t)lane, w + 0)];
+                q.y = oring[seg_slot((uint32_t)lane, w + 1)];
+                q.z = oring[seg_slot((uint32_t)lane, w + 2)];
+                q.w = oring[seg_slot((uint32_t)lane, w + 3)];
+                if (vs >= pad && vs + 16 <= vend) {
+                    *reinterpret_cast<uint4*>(line0 + vs) = q;
+                } else {
+                    for (uint32_t k = 0; k < 16; k++) {
+                        const uint32_t word = k < 4 ? q.x : (k < 8 ? q.y : (k < 12 ? q.z : q.w));
+                        if (vs + k >= pad && vs + k < vend) line0[vs + k] = (uint8_t)(word >> (8 * (k & 3)));
+                    }
+                }
+            };
+            auto drain = [&]() __attribute__((always_inline)) {
+                while (__any(4 * vposw - vstored >= 16)) {
+                    if (4 * vposw - vstored >= 16) {
+                        store_piece(vstored);
+                        vstored += 16;
+                    }
+                }
+            };
+            if (live) rd.start(in, seg_bit0 + pos);
+            while (__any(pos < my_end || fill != 0)) {
+                if (++guard > (1u << 20)) return ST_INVALID_LITERAL_LENGTH_CODE;  // cannot happen; never hang
+                drain();
+                if (__any(fill >= 64)) {  // a long hole: whole zero lines straight to the slot
+                    if (fill >= 64) {
+                        oring[seg_slot((uint32_t)lane, vposw)] = acc;
+                        vposw++;
+                        fill -= 4 - (sh >> 3);
+                        acc = 0;
+                        sh = 0;
+                        while (vposw & 3) {
+                            oring[seg_slot((uint32_t)lane, vposw)] = 0;
+                            vposw++;
+                            fill -= 4;
+                        }
+                        while (4 * vposw != vstored) {
+                            store_piece(vstored);
+                            vstored += 16;
+                        }
+                        uint32_t lines = min(fill, vend - vstored) >> 4;
+                        const uint32_t m = lines << 4;
+                        uint8_t* dst = line0 + vstored;
+                        for (; lines; lines--, dst += 16) *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+                        vstored += m;
+                        vposw += m >> 2;
+                        fill -= m;
+                    }
+                }
+                span_events(rd, live && (pos < my_end || fill != 0));
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t nw = rd.peek();
+                    SpanTok t = span_token(span_window(rd, nw));
+                    // same stepping as the counted chains: single literals close to the window's end, so
+                    // that this pass crosses the window on x0 and then follows the counted tail exactly
+                    const bool single = t.kind == 0 && t.n == 2 && pos < (uint32_t)kSegWindow && pos + 24 >= (uint32_t)kSegWindow;
+                    t.bits_a = single ? t.n1 : t.bits_a;
+                    t.n = single ? 1u : t.n;
+                    t.lits = single ? (t.lits & 0xFF) : t.lits;
+                    const bool filling = fill != 0;
+                    const bool dec = live && !filling && pos < my_end;
+                    const bool is_match = dec && t.kind == 1;
+                    if (is_match) {
+                        span_list[2 * mi] = opos + obase + produced;
+                        span_list[2 * mi + 1] = t.length | (t.dist << 16);
+                        mi++;
+                    }
+                    const uint32_t nf = min(fill, 4u);
+                    const uint32_t n = filling ? nf : (dec && t.kind == 0 ? t.n : 0u);
+                    const uint32_t v = (!filling && dec && t.kind == 0) ? t.lits : 0u;
+                    fill = filling ? fill - nf : (is_match ? t.length : 0u);
+                    produced += dec ? (t.kind == 1 ? t.length : (t.kind == 0 ? t.n : 0u)) : 0u;
+                    rd.advance(dec ? t.bits_a : 0u, nw);
+                    if (__any(is_match)) {
+                        const uint32_t nw2 = rd.peek();
+                        rd.advance(is_match ? t.bits_b : 0u, nw2);
+                    }
+                    pos += dec ? t.bits_a + t.bits_b : 0u;
+                    const uint64_t tt = (uint64_t)v << sh;
+                    acc |= (uint32_t)tt;
+                    oring[seg_slot((uint32_t)lane, vposw)] = acc;
+                    const uint32_t tot8 = sh + 8 * n;
+                    const bool full = tot8 >= 32;
+                    acc = full ? (uint32_t)(tt >> 32) : acc;
+                    vposw += full ? 1u : 0u;
+                    sh = tot8 & 31;
+                }
+            }
+            drain();
+            if (live) {
+                oring[seg_slot((uint32_t)lane, vposw)] = acc;
+                for (uint32_t w = vposw + 1; (w & 3) != 0; w++) oring[seg_slot((uint32_t)lane, w)] = 0;
+                if (vstored < vend) store_piece(vstored);
+            }
+            // a disagreement between the passes would be a bug; never publish such a span
+            if (__any(live && (4 * vposw + (sh >> 3) != vend || produced != count))) return ST_INVALID_LITERAL_LENGTH_CODE;
+        }
+        SPHASE(12);
+        // ---- pass 3: matches, in stream order, 64 at a time against the "resolved up to" frontier ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        {
+            uint8_t* const o = out_al + gmis;  // o[p] = output byte p of this stream
+            for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                const bool mine = j < nmatch;
+                uint32_t at = 0xFFFFFFFFu, ld = 0;
+                if (mine) {
+                    at = __hip_atomic_load(span_list + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ld = __hip_atomic_load(span_list + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const uint32_t length = ld & 0xFFFF, dist = ld >> 16;
+                if (__any(mine && dist > at)) return ST_DISTANCE_TOO_FAR_BACK;  // src/decompress.rs:782
+                const uint32_t src_end = at - dist + min(length, dist);
+                const float inv_d = 1.0f / (float)max(dist, 1u);
+                bool done = !mine;
+                for (uint32_t rounds = 0;; rounds++) {
+                    if (rounds > 2 * kWave) return ST_INVALID_LITERAL_LENGTH_CODE;  // cannot happen; never hang
+                    uint32_t F = done ? 0xFFFFFFFFu : at;  // first unresolved match of the batch
+#pragma unroll
+                    for (int x = 32; x > 0; x >>= 1) F = min(F, (uint32_t)__shfl_xor(F, x, kWave));
+                    if (F == 0xFFFFFFFFu) break;
+                    const bool ready = !done && (at == F || src_end <= F);
+                    // out[at + k] = out[at - dist + k mod dist]: every source byte lies in front of `at`
+                    for (uint32_t c = 0; __any(ready && c < length); c += 16) {
+                        uint32_t b[16];
+#pragma unroll
+                        for (uint32_t k = 0; k < 16; k++) {
+                            const uint32_t kk = (ready && c + k < length) ? c + k : 0u;
+                            uint32_t r = kk;
+                            if (dist < length) {  // kk mod dist for kk < 258 (quotient estimate off by at most one)
+                                const uint32_t q = (uint32_t)((float)kk * inv_d);
+                                r = kk - q * dist;
+                                r = (int32_t)r < 0 ? r + dist : r;
+                                r = r >= dist ? r - dist : r;
+                            }
+                            const uint8_t* sp = (ready && c + k < length) ? o + (at - dist + r) : o;
+                            b[k] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 16; k++) {
+                            if (ready && c + k < length) o[at + c + k] = (uint8_t)b[k];
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next round reads these bytes
+                    done = done || ready;
+                }
+            }
+        }
+        SPHASE(13);
+        GSTAT(15, nmatch);
+        // ---- Adler-32 of the new bytes, output ring, input window ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const uint32_t q_lo = opos + gmis, q_hi = opos + total + gmis;
+            for (uint32_t it = q_lo & ~15u; it < q_hi; it += kWave * 16) {
+                const uint32_t lq = it + (uint32_t)lane * 16;
+                const uint32_t blk_hi = min(q_hi, it + kWave * 16), blk_lo = max(q_lo, it);
+                uint32_t sum = 0, wsum = 0;
+                if (lq < blk_hi && lq + 16 > blk_lo) {
+                    const uint32_t lo = (blk_lo > lq) ? blk_lo - lq : 0, hi = (blk_hi < lq + 16) ? blk_hi - lq : 16;
+                    const uint32_t W = blk_hi - lq;  // weight of byte j is W - j
+                    if (lo == 0 && hi == 16) {
+                        const uint32_t* lp = reinterpret_cast<const uint32_t*>(out_al + lq);
+                        const uint32_t vx = __hip_atomic_load(lp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t vy = __hip_atomic_load(lp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t vz = __hip_atomic_load(lp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t vw = __hip_atomic_load(lp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sum = bytesum4(vx) + bytesum4(vy) + bytesum4(vz) + bytesum4(vw);
+                        uint32_t u = bytedot4(vx, 0x03020100u, 0);
+                        u = bytedot4(vy, 0x07060504u, u);
+                        u = bytedot4(vz, 0x0b0a0908u, u);
+                        u = bytedot4(vw, 0x0f0e0d0cu, u);
+                        wsum = W * sum - u;
+                    } else {
+                        for (uint32_t b4 = lo; b4 < hi; b4++) {
+                            const uint32_t b = __hip_atomic_load(out_al + lq + b4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            sum += b;
+                            wsum += (W - b4) * b;
+                        }
+                    }
+                }
+                const uint32_t S = wave_sum_u32(sum), Tt = wave_sum_u32(wsum);
+                const uint32_t Lb = blk_hi - blk_lo;
+                adler_b = (uint32_t)(((uint64_t)adler_b + (uint64_t)Lb * adler_a + Tt) % kAdlerMod);
+                adler_a = (adler_a + S) % kAdlerMod;
+            }
+        }
+        opos += total;
+        flushed = opos;
+        wave_sync();
+        span_reload_out_ring();
+        // ---- where the stream continues ----
+        const int last = nlive - 1;
+        const uint32_t last_pos = __shfl(tail.pos, last, kWave);
+        const uint32_t last_stop = __shfl(tail.stop, last, kWave), last_bits = __shfl(tail.stop_bits, last, kWave);
+        uint32_t used = (uint32_t)last * seg + last_pos;
+        uint32_t rc = RC_OK;
+        // with the slot exactly full the end-of-block symbol is left to serial_token (see tile_step)
+        if (last_stop == 1 && opos != cap) {
+            used += last_bits;
+            rc = RC_EOB;
+        }
+        left -= used;
+        progress = used;
+        seek(P64 + used);
+        SPHASE(14);
+        return rc;
+    }
+
     // ------------------------------------------------------------------ compressed block data
     template <bool TILES>
     __device__ __forceinline__ uint32_t decode_block_data() {
         for (;;) {
+            if (TILES && span_list && span_credit == 0 && serial_credit == 0 && opos < cap) {
+                uint32_t progress;
+#ifdef FDH_DEBUG_TILES
+                const long long ts = clock64();
+#endif
+                uint32_t rc = span_step(progress);
+#ifdef FDH_DEBUG_TILES
+                GSTAT(3, 1);
+                GSTAT(4, progress);
+                GSTAT(7, clock64() - ts);
+#endif
+                if (rc != RC_OK) return rc;
+                if (progress) continue;
+                if (span_credit == 0) span_credit = 8;
+            }
             if (TILES && serial_credit == 0 && opos < cap) {
                 uint32_t progress;
+                if (span_credit && span_credit != ~0u) span_credit--;
 #ifdef FDH_DEBUG_TILES
                 const long long t0 = clock64();
 #endif

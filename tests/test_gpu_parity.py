@@ -138,7 +138,7 @@ def test_valid_streams_every_decoder_variant(harness):
             names.append("%s@%d" % (name, c))
             blobs.append(comp)
             caps.append(c)
-    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8):
+    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8, 256, 256 | 8, 256 | 4 | 8):  # 256: span decoder (experimental)
         harness.assert_inflate_parity(names, blobs, caps, flags=flags)
 
 
