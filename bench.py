@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing: run the RCCL metadata gather even with one rank")
     return ap.parse_args()
 
 
@@ -120,9 +122,11 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n, L = args.streams, args.stream_bytes
     raw, r_off, comp, c_off, clen = build_inputs(args, rank, dev)
@@ -140,13 +144,13 @@ def main():
             fd.inflate_batch(comp, c_off, out, r_off, out_len, status, adler, flags=args.flags)
         else:
             fd.deflate_ultrafast_batch(raw.view(-1), r_off, enc_out, enc_off, out_len)
-        if world > 1:
+        if use_dist:
             return fdist.gather_metadata(status, out_len, adler)
         return None
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -221,7 +225,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

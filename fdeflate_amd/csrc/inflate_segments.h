@@ -432,8 +432,8 @@ __device__ __forceinline__ uint32_t seg_count_group(uint32_t left, uint32_t lim,
 }
 
 // Up to `left` literal-only steps of the writing loop (pass 2), hand-scheduled like
-// seg_count_group: decode one entry, append its 1-2 bytes to the 4-byte accumulator, keep the
-// (possibly partial) accumulator in the output ring, move on to the next ring word when it is full.
+// seg_count_group: decode one entry, append its 1-2 bytes to the 4-byte accumulator, move the
+// accumulator to the output ring when it is full (a partial one stays in its register).
 // Entered only while no lane is filling a run.  Returns the steps still to do when some running
 // lane meets a special entry (nothing of that step applied).
 struct SegWriter {
@@ -466,7 +466,6 @@ __device__ __forceinline__ uint32_t seg_write_group(uint32_t left, uint32_t end2
         "  v_lshrrev_b32 %[v], 16, %[e]\n"
         "  v_lshlrev_b32 %[t], %[sh], %[v]\n"
         "  v_or_b32 %[acc], %[acc], %[t]\n"
-        "  ds_write_b32 %[wa], %[acc]\n"
         "  v_sub_u32 %[t], 32, %[sh]\n"
         "  v_lshrrev_b32 %[v], %[t], %[v]\n"  // bytes that did not fit (only used when the word fills up, sh > 0)
         "  v_lshrrev_b32 %[t], 8, %[e]\n"
@@ -475,7 +474,8 @@ __device__ __forceinline__ uint32_t seg_write_group(uint32_t left, uint32_t end2
         "  v_cmp_lt_u32 vcc, 31, %[sh]\n"
         "  v_and_b32 %[sh], 31, %[sh]\n"
         "  s_mov_b64 %[sr], exec\n"
-        "  s_and_b64 exec, exec, vcc\n"  // lanes whose accumulator is full
+        "  s_and_b64 exec, exec, vcc\n"  // lanes whose accumulator is full: it goes to the ring
+        "  ds_write_b32 %[wa], %[acc]\n"
         "  v_mov_b32 %[acc], %[v]\n"
         "  v_add_u32 %[t], 0x100, %[wa]\n"
         "  v_and_b32 %[t], 0xf00, %[t]\n"
