@@ -232,10 +232,7 @@ __global__ __launch_bounds__(kLaneBlock) void inflate_lanes_kernel(LaneArgs a) {
 
 // Canonical streams, segment-parallel: one stream per wavefront, one segment per lane
 // (inflate_segments.h).
-#ifndef FDH_SEG_WAVES_PER_SIMD
-#define FDH_SEG_WAVES_PER_SIMD 4
-#endif
-__global__ __launch_bounds__(kSegWaves* kWave, FDH_SEG_WAVES_PER_SIMD) void inflate_segments_kernel(SegArgs a) {
+__global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(SegArgs a) {
     __shared__ SegLds lds;
     {  // stage the canonical table, converted to this kernel's entry layout
         const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit);

@@ -43,24 +43,15 @@ __device__ uint32_t g_segtime[4096 * 8];
 #define SEGDBG_ADD(slot, val) do { } while (0)
 #endif
 
-#ifndef FDH_SEG_WAVES
-#define FDH_SEG_WAVES 8
-#endif
-#ifndef FDH_SEG_RING
-#define FDH_SEG_RING 16
-#endif
-constexpr int kSegWaves = FDH_SEG_WAVES;   // wavefronts (= streams) per workgroup
-constexpr int kSegInWords = FDH_SEG_RING;  // per-lane input ring, dwords
-constexpr int kSegOutWords = FDH_SEG_RING; // per-lane output ring, dwords
+constexpr int kSegWaves = 8;      // wavefronts (= streams) per workgroup: 80 KiB of LDS, two workgroups per CU
+constexpr int kSegInWords = 16;   // per-lane input ring, dwords
+constexpr int kSegOutWords = 16;  // per-lane output ring, dwords
 constexpr int kSegChunk = kSegInWords / 4; // dwords per global load of a lane (a quarter of the ring)
 constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation
 constexpr int kSegSteps = kSegInWords / 2;  // table look-ups between two global-memory events
 constexpr uint32_t kSegNeed = (kSegSteps * 18 + 31) / 32;  // dwords a group of steps can consume (18 bits/token)
 constexpr uint32_t kSegMinBits = 4 * kSegWindow;  // aim: no segment shorter than this (fewer lanes are used instead)
-#ifndef FDH_BULK
-#define FDH_BULK 64
-#endif
-constexpr uint32_t kSegBulkFill = FDH_BULK;             // runs at least this long are stored line by line
+constexpr uint32_t kSegBulkFill = 64;             // runs at least this long are stored line by line
 constexpr uint32_t kNoByte = 0x100;  // "no literal seen yet"
 
 // Table entry of this kernel (converted from the device layout of inflate_tables.h while staging).
@@ -94,9 +85,6 @@ struct SegLds {
     uint32_t lit[kLitSize];
     uint32_t in_ring[kSegWaves * kSegInWords * kWave];
     uint32_t out_ring[kSegWaves * kSegOutWords * kWave];
-#ifdef FDH_SEG_PAD_LDS
-    uint32_t pad[FDH_SEG_PAD_LDS / 4];
-#endif
 };
 static_assert((kSegInWords == 16 || kSegInWords == 8) && kSegOutWords == kSegInWords && kWave == 64, "ring addressing");
 __device__ __forceinline__ uint32_t seg_slot(uint32_t lane_off, uint32_t word) {
@@ -206,7 +194,6 @@ struct SegReader {
     // Synchronous top-up (once, between the window walk and the long counting loop): commits what is
     // in flight, then loads until the ring is full.
     __device__ __forceinline__ void refill_now() {
-#ifndef FDH_SEG_SINGLELOAD
         if (has_a) {  // a pair is in flight: take it if it fits, otherwise ask again below
             if ((uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)(2 * kSegChunk)) {
                 put(pend_a);
@@ -215,10 +202,6 @@ struct SegReader {
                 gp -= 8 * kSegChunk;
             }
         }
-#else
-        if (has_a) put(pend_a);
-        if (has_b) put(pend_b);
-#endif
         has_a = has_b = false;
         while ((uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)kSegChunk) {
             put(seg_load(gp, buf_lo, buf_hi));
@@ -240,7 +223,6 @@ struct SegReader {
         hi = wrap ? nw : hi;
         in_rd += wrap ? 1u : 0u;
     }
-#ifndef FDH_SEG_SINGLELOAD
     // Wavefront-uniform event, pair policy: two adjacent chunks (one 32-B sector of a 16-dword ring's
     // lane) are requested together and committed together once the ring has room for both, so a
     // 128-B line of input is visited 4 times instead of 8.  has_a == has_b at all times.
@@ -257,20 +239,6 @@ struct SegReader {
             has_a = has_b = true;
         }
     }
-#else
-    // Wavefront-uniform event: commit what was requested two events ago, request the next chunk.
-    __device__ __forceinline__ void event(bool want_more) {
-        if (has_a) put(pend_a);
-        pend_a = pend_b;
-        has_a = has_b;
-        has_b = false;
-        if (want_more && (uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)(has_a ? 2 * kSegChunk : kSegChunk)) {
-            pend_b = seg_load(gp, buf_lo, buf_hi);
-            gp += 4 * kSegChunk;
-            has_b = true;
-        }
-    }
-#endif
     // One event per kSegSteps steps keeps up with a chunk per group; a group can consume up to
     // kSegSteps * 18 bits = kSegNeed dwords, so denser stretches get extra (waiting) events.
     __device__ __forceinline__ void events(bool running) {
@@ -570,11 +538,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     const uint32_t lane_off = (uint32_t)wid * (kSegInWords * kWave) + (uint32_t)lane;  // ring slot of word 0
 
     // ---- stream set-up (uniform) ----
-#ifdef FDH_EXP_SAMEIN
-    const uint64_t i0 = a.in_off[sid & 255], i1 = a.in_off[(sid & 255) + 1];  // timing experiment: L2-resident input
-#else
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
-#endif
     const uint64_t o0 = a.out_off[sid], o1 = a.out_off[sid + 1];
     const uint8_t* in = a.in + i0;
     uint8_t* op = a.out + o0;
@@ -773,9 +737,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
         q.z = oring[seg_slot(lane_off, w + 2)];
         q.w = oring[seg_slot(lane_off, w + 3)];
         if (vs >= pad && vs + 16 <= vend) {
-#ifndef FDH_EXP_NOSTORE
             *reinterpret_cast<uint4*>(line0 + vs) = q;
-#endif
         } else {  // first / last line of this lane: only its own bytes
             for (uint32_t k = 0; k < 16; k++) {
                 const uint32_t word = k < 4 ? q.x : (k < 8 ? q.y : (k < 12 ? q.z : q.w));
@@ -804,7 +766,6 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             }
         }
     };
-#ifndef FDH_SEG_DRAIN16
     // Lines leave in 32-B aligned pairs (two adjacent 16-B stores back to back) so that whole
     // 32-B sectors reach the L2 together; a lane whose first line is the upper half of a sector
     // sends that one alone.  < 32 B stay behind, + <= 32 B per group of steps: fits the 64-B ring.
@@ -825,9 +786,6 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             }
         }
     };
-#else
-    auto drain = drain_all;
-#endif
     // A long dist-1 run (src/decompress.rs:793-801 fills it with one byte): bring the lane to a
     // 16-B line boundary through the ring, then store whole lines of the byte directly; their
     // Adler-32 contribution has a closed form.

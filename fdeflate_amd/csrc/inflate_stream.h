@@ -852,15 +852,6 @@ struct Inflater {
         {
             const uint32_t ring_top = opos + total;
             const int64_t ring_lo = (int64_t)ring_top - kOutRing;
-#ifdef FDH_NO_PHASE_A
-            for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
-                const uint32_t j = j0 + (uint32_t)lane;
-                const bool mine = j < nmatch;
-                const uint32_t m0 = mine ? io.mlist[2 * j] : 0u, dist = mine ? io.mlist[2 * j + 1] : 1u;
-                if (__any(mine && dist > opos + (m0 & 0xFFFF))) return ST_DISTANCE_TOO_FAR_BACK;
-            }
-            (void)ring_lo;
-#else
             for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
                 const uint32_t j = j0 + (uint32_t)lane;
                 const bool mine = j < nmatch;
@@ -897,7 +888,6 @@ struct Inflater {
                     io.mlist[2 * j] = m0 & 0xFFFF;  // length 0: done
                 }
             }
-#endif
             wave_sync();
         }
         TPHASE(7);
