@@ -33,6 +33,7 @@ FLAG_NO_LANES = 32
 FLAG_FIRST_ONLY = 64
 FLAG_NO_SEGMENTS = 128
 FLAG_SPANS = 256
+FLAG_NO_FAST_GENERAL = 512
 
 
 class DecompressionError(Exception):

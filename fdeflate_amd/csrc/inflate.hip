@@ -93,9 +93,11 @@ __device__ __forceinline__ bool needs_serial_recheck(const StreamResult& r, uint
     return true;
 }
 
+constexpr int kSpanRingBytes = (kSegInWords + kSegOutWords) * kWave * 4;  // the span decoder's rings overlay `io`
 struct GeneralLds {
     TableSet tables;
     WaveIo io;
+    uint8_t span_pad[kSpanRingBytes > (int)sizeof(WaveIo) ? kSpanRingBytes - (int)sizeof(WaveIo) : 16];
     HeaderScratch hs;
 };
 
@@ -142,6 +144,52 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
         a.status[sid] = r.status;
         a.out_len[sid] = r.out_len;
         if (a.adler) a.adler[sid] = r.adler;
+    }
+}
+
+// Fast general kernel: the same decoder with a 10-bit literal/length table (4 KiB instead of 16 KiB:
+// 16.7 KiB of LDS per stream, 9 workgroups per CU instead of 5 -- the tile decoder is latency-bound,
+// so occupancy is throughput).  Codes longer than 10 bits are resolved by the canonical walk.  Its
+// double-literal pairing is not the reference's, so every result that needs the exact serial
+// decoder is left PENDING_SERIAL for inflate_general_kernel.
+constexpr int kFastLitBits = 10;
+struct GeneralFastLds {
+    TableSetT<kFastLitBits> tables;
+    WaveIo io;
+    uint8_t span_pad[kSpanRingBytes > (int)sizeof(WaveIo) ? kSpanRingBytes - (int)sizeof(WaveIo) : 16];
+    HeaderScratch hs;
+};
+__global__ __launch_bounds__(kWave) void inflate_general_fast_kernel(InflateBatchArgs a) {
+    __shared__ GeneralFastLds lds;
+    const int lane = threadIdx.x;
+    const uint64_t sid = blockIdx.x;
+    if (sid >= a.n) return;
+    if (a.only_pending && a.status[sid] != kPending) return;
+    const StreamArgs s = stream_args(a, sid);
+    InflaterT<kFastLitBits> inf(lds.tables, lds.io, &lds.hs, lane);
+    uint32_t slot = kSpanSlots;
+    if (a.span_pool && (a.flags & 0x100u) && s.in_len >= 4096) {
+        if (lane == 0) {
+            slot = (uint32_t)(sid % kSpanSlots);
+            while (atomicCAS(&a.span_pool[slot], 0u, 1u) != 0u) slot = (slot + 1) % kSpanSlots;
+        }
+        slot = uni(slot);
+        inf.span_list = a.span_pool + kSpanSlots + (size_t)slot * (2 * kSpanMaxMatches);
+    }
+    inf.init(s);
+    const StreamResult r = inf.run<true, false>();
+    if (slot < kSpanSlots) {
+        __threadfence();
+        if (lane == 0) atomicExch(&a.span_pool[slot], 0u);
+    }
+    if (lane == 0) {
+        if (needs_serial_recheck(r, a.flags)) {
+            a.status[sid] = kPendingSerial;
+        } else {
+            a.status[sid] = r.status;
+            a.out_len[sid] = r.out_len;
+            if (a.adler) a.adler[sid] = r.adler;
+        }
     }
 }
 
@@ -420,6 +468,11 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             a.list = nullptr;
             (void)hipFreeAsync(list, stream);
             if (e != hipSuccess) return (int)e;
+            if (!(flags & 0x200u)) {
+                hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
+                e = hipGetLastError();
+                if (e != hipSuccess) return (int)e;
+            }
             hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
             return (int)hipGetLastError();
         }
@@ -447,6 +500,11 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     a.only_pending = 1;
+    if (!(flags & 0x200u)) {
+        hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
     return (int)hipGetLastError();
 }

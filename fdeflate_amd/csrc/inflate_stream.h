@@ -33,15 +33,16 @@ constexpr int kInRingDw = 2 * kInChunk / 4; // two chunks
 constexpr int kOutRing = 4096;              // bytes, power of two
 constexpr int kOutMask = kOutRing - 1;
 constexpr int kFlushSlack = 64;
-constexpr int kMaxMatches = 256;            // match tokens replayed per tile
+constexpr int kMaxMatches = 192;            // match tokens replayed per tile (8 x WaveIo + tables <= 80 KiB in the canon kernel)
 constexpr int kTileBits = 64;               // stream bits owned by one lane of a tile
 constexpr uint32_t kSpanSegBits = 1024;     // stream bits owned by one lane of a span
 constexpr uint32_t kSpanMinSeg = 512;       // shorter segments: not worth a span, tiles take over
 constexpr uint32_t kSpanMaxMatches = 8192;  // match tokens per span (scratch list capacity)
 
 // Decode tables of the current block.
-struct __attribute__((aligned(16))) TableSet {
-    uint32_t lit[kLitSize];
+template <int LB>
+struct __attribute__((aligned(16))) TableSetT {
+    uint32_t lit[1 << LB];
     uint32_t dist[kDistSize];
     CodeBook lit_cb;
     CodeBook dist_cb;
@@ -49,6 +50,7 @@ struct __attribute__((aligned(16))) TableSet {
     uint16_t dist_sorted[32];
     uint32_t eof[4];  // code, mask, bits of the end-of-block symbol (reference eof_code/mask/bits)
 };
+using TableSet = TableSetT<kLitBits>;
 
 // Per-wavefront staging.
 struct __attribute__((aligned(16))) WaveIo {
@@ -145,8 +147,15 @@ __device__ __forceinline__ FlushState flush_ring(WaveIo* iop, uint8_t* out_al, u
 }
 
 // ---------------------------------------------------------------------------------------
-struct Inflater {
-    TableSet& T;
+// LB = index bits of the literal/length table.  12 reproduces the reference's tables (and its
+// double-literal pairing, which the exact serial decoder relies on); the fast general kernel uses
+// a smaller table for occupancy and resolves longer codes by the canonical walk.
+template <int LB>
+struct InflaterT {
+    static constexpr int kLB = LB;
+    static constexpr uint32_t kLSize = 1u << LB;
+    using LitTraits = LitlenTraitsT<LB>;
+    TableSetT<LB>& T;
     WaveIo& io;
     HeaderScratch* hs;
     const int lane;
@@ -176,7 +185,7 @@ struct Inflater {
     uint32_t* span_list;     // scratch of this workgroup: kSpanMaxMatches x {at, length | dist << 16}; null: no spans
     uint32_t span_credit;    // tiles to run before the next span attempt (after a span that did not pay)
 
-    __device__ __forceinline__ Inflater(TableSet& t, WaveIo& w, HeaderScratch* h, int ln)
+    __device__ __forceinline__ InflaterT(TableSetT<LB>& t, WaveIo& w, HeaderScratch* h, int ln)
         : T(t), io(w), hs(h), lane(ln), span_list(nullptr) {}
 
     // ------------------------------------------------------------------ input window
@@ -324,9 +333,9 @@ struct Inflater {
     __device__ __forceinline__ uint32_t build_block_tables(uint32_t hlit) {
         const uint8_t* lens = hs->lens;
         if (uni(lens[256]) == 0) return ST_BAD_LITERAL_LENGTH_HUFFMAN_TREE;
-        if (build_table<LitlenTraits, false>(T.lit, lens, (int)hlit, T.lit_cb, T.lit_sorted, lane) != BUILD_OK)
+        if (build_table<LitTraits, false>(T.lit, lens, (int)hlit, T.lit_cb, T.lit_sorted, lane) != BUILD_OK)
             return ST_BAD_CODE_LENGTH_HUFFMAN_TREE;  // sic, src/decompress.rs:579
-        add_double_literals(T.lit, lane);
+        add_double_literals<LB>(T.lit, lane);
         // code of the end-of-block symbol, as the reference keeps it (eof_code/mask/bits)
         uint32_t l256 = uni(lens[256]);
         uint32_t rank = 0;
@@ -512,7 +521,7 @@ struct Inflater {
             }
             return RC_STUCK;
         }
-        uint32_t e = uni(T.lit[(uint32_t)bb & (kLitSize - 1)]);
+        uint32_t e = uni(T.lit[(uint32_t)bb & (kLSize - 1)]);
         uint32_t nb = e & 15, kind = (e >> 4) & 15;
         if (kind == K_LIT1) {
             if (left < nb) return RC_STUCK;
@@ -626,10 +635,10 @@ struct Inflater {
         // (the reference's secondary tables, src/huffman.rs:138-181): the result is the entry the
         // symbol would have had in a wide enough primary table.
         auto lit_at = [&](uint32_t w) __attribute__((always_inline)) -> uint32_t {
-            uint32_t e = T.lit[w & (kLitSize - 1)];
+            uint32_t e = T.lit[w & (kLSize - 1)];
             if (((e >> 4) & 15) == K_LONG) {
                 uint32_t sym, len;
-                if (long_walk(T.lit_cb, T.lit_sorted, w, kLitBits + 1, sym, len)) e = LitlenTraits::entry(sym, len);
+                if (long_walk(T.lit_cb, T.lit_sorted, w, LB + 1, sym, len)) e = LitTraits::entry(sym, len);
             }
             return e;
         };
@@ -969,10 +978,10 @@ struct Inflater {
     __device__ __forceinline__ SpanTok span_token(uint64_t w) {
         SpanTok t;
         t.bits_b = t.n = t.lits = t.n1 = t.length = t.dist = 0;
-        uint32_t e = T.lit[(uint32_t)w & (kLitSize - 1)];
+        uint32_t e = T.lit[(uint32_t)w & (kLSize - 1)];
         if (((e >> 4) & 15) == K_LONG) {
             uint32_t sym, len;
-            if (long_walk(T.lit_cb, T.lit_sorted, (uint32_t)w, kLitBits + 1, sym, len)) e = LitlenTraits::entry(sym, len);
+            if (long_walk(T.lit_cb, T.lit_sorted, (uint32_t)w, LB + 1, sym, len)) e = LitTraits::entry(sym, len);
         }
         const uint32_t nb = e & 15, k = (e >> 4) & 15;
         t.bits_a = nb;
@@ -1115,7 +1124,7 @@ struct Inflater {
         for (int k = 0; k < kSegChunk; k++) rd.pend_a.w[k] = rd.pend_b.w[k] = 0;
         rd.has_a = rd.has_b = false;
         uint32_t* const oring = reinterpret_cast<uint32_t*>(&io) + kSegInWords * kWave;
-        static_assert(sizeof(WaveIo) >= (kSegInWords + kSegOutWords) * kWave * 4, "span rings overlay the staging rings");
+        // (the span rings overlay the staging rings: a kernel that enables spans keeps 8 KiB at &io)
         loaded = 0;  // the input window is gone (seek() below reloads it)
 
 #ifdef FDH_DEBUG_SPAN
@@ -1548,5 +1557,6 @@ struct Inflater {
         return finish(rc, stored);
     }
 };
+using Inflater = InflaterT<kLitBits>;
 
 }  // namespace fdh

@@ -41,8 +41,9 @@ struct CodeBook {
     uint32_t run[16];    // scratch: symbols of each length placed so far
 };
 
-struct LitlenTraits {
-    static constexpr int kBits = kLitBits;
+template <int LB>
+struct LitlenTraitsT {
+    static constexpr int kBits = LB;
     __device__ static uint32_t entry(uint32_t sym, uint32_t nb) {
         if (sym < 256) return nb | (K_LIT1 << 4) | (sym << 8) | (nb << 24);
         if (sym == 256 || sym >= 286) return nb | (K_EOB << 4);  // 286/287: parity trap 1
@@ -51,6 +52,7 @@ struct LitlenTraits {
     }
     __device__ static uint32_t long_entry() { return K_LONG << 4; }
 };
+using LitlenTraits = LitlenTraitsT<kLitBits>;
 struct DistTraits {
     static constexpr int kBits = kDistBits;
     __device__ static uint32_t entry(uint32_t sym, uint32_t nb) {
@@ -156,8 +158,9 @@ __device__ __forceinline__ int build_table(uint32_t* table, const uint8_t* lens,
 
 // Second pass for the litlen table: turn single-literal entries into double-literal entries
 // wherever the next symbol is also a literal and both codes fit in kLitBits bits.
+template <int LB = kLitBits>
 __device__ __forceinline__ void add_double_literals(uint32_t* table, int lane) {
-    for (int idx = lane; idx < kLitSize; idx += kWave) {
+    for (int idx = lane; idx < (1 << LB); idx += kWave) {
         uint32_t e1 = table[idx];
         uint32_t k1 = (e1 >> 4) & 15;
         uint32_t n1 = (k1 == K_LIT1) ? (e1 >> 24) : 0;  // [27:24] = bits of the first symbol
@@ -165,7 +168,7 @@ __device__ __forceinline__ void add_double_literals(uint32_t* table, int lane) {
         uint32_t k2 = (e2 >> 4) & 15;
         uint32_t n2 = e2 >> 24;
         wave_sync();  // every lane has read before any lane rewrites an entry
-        if (k1 == K_LIT1 && (k2 == K_LIT1 || k2 == K_LIT2) && n1 + n2 <= (uint32_t)kLitBits) {
+        if (k1 == K_LIT1 && (k2 == K_LIT1 || k2 == K_LIT2) && n1 + n2 <= (uint32_t)LB) {
             uint32_t s1 = (e1 >> 8) & 0xFF, s2 = (e2 >> 8) & 0xFF;
             table[idx] = (n1 + n2) | (K_LIT2 << 4) | (s1 << 8) | (s2 << 16) | (n1 << 24);
         }
