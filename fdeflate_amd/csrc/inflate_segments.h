@@ -356,6 +356,7 @@ __device__ __forceinline__ uint32_t seg_count_group(uint32_t left, uint32_t lim,
     uint32_t w2, e, nw, t;
     uint64_t sv;
     asm volatile(
+        "  s_waitcnt lgkmcnt(0)\n"  // nothing of the compiler's may be in flight: the counted waits below assume it
         "Lstep_%=:\n"
         "  v_alignbit_b32 %[w2], %[hi], %[lo], %[b]\n"
         "  v_and_b32 %[t], 0x3ffc, %[w2]\n"
@@ -415,6 +416,7 @@ __device__ __forceinline__ uint32_t seg_write_group(uint32_t left, uint32_t end2
     uint32_t w2, e, nw, t, v;
     uint64_t sv, sr;
     asm volatile(
+        "  s_waitcnt lgkmcnt(0)\n"  // nothing of the compiler's may be in flight: the counted waits below assume it
         "Lstep_%=:\n"
         "  v_alignbit_b32 %[w2], %[hi], %[lo], %[b]\n"
         "  v_and_b32 %[t], 0x3ffc, %[w2]\n"
