@@ -214,7 +214,7 @@ def main():
                        "sharding": "contiguous stream ranges per rank, metadata all_gather per step"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "inflate_segments_kernel (+ inflate_canon_kernel / inflate_general_kernel mop-up, one fdh_inflate_batch launch)"
+                         "kernel": "inflate_segments_kernel (+ inflate_canon_kernel / inflate_general_fast_kernel / inflate_general_kernel follow-ups, one fdh_inflate_batch launch)"
                          if args.mode == "decode" else "deflate_ultrafast_kernel",
                          "kernel_ms_avg": round(kern_avg_ms, 4), "algorithmic_bytes_per_launch": alg},
         }
