@@ -46,7 +46,7 @@ __device__ uint32_t g_segtime[4096 * 8];
 constexpr int kSegWaves = 8;      // wavefronts (= streams) per workgroup: 80 KiB of LDS, two workgroups per CU
 constexpr int kSegInWords = 16;   // per-lane input ring, dwords
 constexpr int kSegOutWords = 16;  // per-lane output ring, dwords
-constexpr int kSegChunk = kSegInWords / 4; // dwords per global load of a lane (a quarter of the ring)
+constexpr int kSegChunk = 4;       // dwords per global load of a lane (16 B)
 constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation
 constexpr int kSegSteps = kSegInWords / 2;  // table look-ups between two global-memory events
 constexpr uint32_t kSegNeed = (kSegSteps * 18 + 31) / 32;  // dwords a group of steps can consume (18 bits/token)
@@ -168,8 +168,10 @@ struct SegReader {
     bool has_a, has_b;
 
     __device__ __forceinline__ void put(const SegChunk& v) {
+        // in_wr is a multiple of the chunk size, so a chunk never wraps: one slot address, constant offsets
+        uint32_t* const p = ring + seg_slot(lane_off, in_wr);
 #pragma unroll
-        for (int k = 0; k < kSegChunk; k++) ring[seg_slot(lane_off, in_wr + k)] = v.w[k];
+        for (int k = 0; k < kSegChunk; k++) p[k * kWave] = v.w[k];
         in_wr += kSegChunk;
     }
     // Positions the reader at stream bit `bit` (relative to the stream's first byte `in`) and
@@ -233,8 +235,21 @@ struct SegReader {
             has_a = has_b = false;
         }
         if (want_more && !has_a) {
-            pend_a = seg_load(gp, buf_lo, buf_hi);
-            pend_b = seg_load(gp + 4 * kSegChunk, buf_lo, buf_hi);
+            if (gp >= buf_lo && gp + 8 * kSegChunk <= buf_hi) {  // one range check for the pair
+                const uint4 va = *reinterpret_cast<const uint4*>(gp);
+                const uint4 vb = *reinterpret_cast<const uint4*>(gp + 4 * kSegChunk);
+                pend_a.w[0] = va.x;
+                pend_a.w[1] = va.y;
+                pend_a.w[2] = va.z;
+                pend_a.w[3] = va.w;
+                pend_b.w[0] = vb.x;
+                pend_b.w[1] = vb.y;
+                pend_b.w[2] = vb.z;
+                pend_b.w[3] = vb.w;
+            } else {
+                pend_a = seg_load(gp, buf_lo, buf_hi);
+                pend_b = seg_load(gp + 4 * kSegChunk, buf_lo, buf_hi);
+            }
             gp += 8 * kSegChunk;
             has_a = has_b = true;
         }
