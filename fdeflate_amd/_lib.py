@@ -36,8 +36,15 @@ def lib():
     L.fdh_ultrafast_bound.argtypes = [u64]
     L.fdh_inflate_batch.restype = C.c_int
     L.fdh_inflate_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, u32, vp]
+    pp = C.POINTER(C.c_void_p)
     L.fdh_deflate_ultrafast_batch.restype = C.c_int
     L.fdh_deflate_ultrafast_batch.argtypes = [vp, vp, vp, vp, vp, u64, vp]
+    L.fdh_stored_size.restype = u64
+    L.fdh_stored_size.argtypes = [u64]
+    L.fdh_deflate_stored_batch.restype = C.c_int
+    L.fdh_deflate_stored_batch.argtypes = [vp, vp, vp, vp, vp, u64, vp]
+    L.fdh_compress_to_vec_stored.restype = C.c_int
+    L.fdh_compress_to_vec_stored.argtypes = [vp, sz, pp, C.POINTER(sz)]
     L.fdh_debug_build_tables.restype = C.c_int
     L.fdh_debug_build_tables.argtypes = [vp, u32, vp, vp, vp, vp]
     pp = C.POINTER(C.c_void_p)
@@ -56,7 +63,7 @@ EXPORTED_SYMBOLS = [
     "fdh_version", "fdh_status_name", "fdh_last_error", "fdh_device_count", "fdh_ultrafast_bound",
     "fdh_inflate_batch", "fdh_deflate_ultrafast_batch", "fdh_debug_build_tables",
     "fdh_decompress_to_vec", "fdh_decompress_to_vec_bounded", "fdh_compress_to_vec_ultra_fast",
-    "fdh_free",
+    "fdh_free", "fdh_stored_size", "fdh_deflate_stored_batch", "fdh_compress_to_vec_stored",
 ]
 
 

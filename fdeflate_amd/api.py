@@ -104,6 +104,20 @@ def ultrafast_bound(n):
     return int(_lib.lib().fdh_ultrafast_bound(int(n)))
 
 
+def compress_to_vec_stored(data):
+    """fdeflate::compress_to_vec_with_level(data, 0) (src/compress/mod.rs:299): stored blocks only."""
+    L = _lib.lib()
+    data = bytes(data)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    _lib.check(L.fdh_compress_to_vec_stored(data, len(data), C.byref(out), C.byref(n)))
+    return _take(out, n.value)
+
+
+def stored_size(n):
+    return int(_lib.lib().fdh_stored_size(int(n)))
+
+
 # ------------------------------------------------------------------------------------------
 # batched device entry points
 # ------------------------------------------------------------------------------------------
@@ -153,6 +167,18 @@ def deflate_ultrafast_batch(raw, in_off, out, out_off, out_len=None):
     stream = _check_dev(raw, in_off, out, out_off, out_len)
     _lib.check(_lib.lib().fdh_deflate_ultrafast_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
                                                      _ptr(out_len), n, C.c_void_p(stream)))
+    return out_len
+
+
+def deflate_stored_batch(raw, in_off, out, out_off, out_len=None):
+    """Level-0 (stored) encode of n buffers (fdh_deflate_stored_batch); returns out_len (int32)."""
+    import torch
+    n = in_off.numel() - 1
+    if out_len is None:
+        out_len = torch.empty(n, dtype=torch.int32, device=raw.device)
+    stream = _check_dev(raw, in_off, out, out_off, out_len)
+    _lib.check(_lib.lib().fdh_deflate_stored_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                                  _ptr(out_len), n, C.c_void_p(stream)))
     return out_len
 
 

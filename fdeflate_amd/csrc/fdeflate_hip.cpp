@@ -18,6 +18,8 @@ int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uint8_t* out, 
 int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status);
 int fdh_launch_build_tables_debug(const uint8_t* code_lengths, uint32_t hlit, uint32_t* litlen, uint32_t* dist,
                                   uint32_t* build_status, hipStream_t stream);
+int fdh_launch_deflate_stored(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                              uint32_t* out_len, uint64_t n, hipStream_t stream);
 int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                                  uint32_t* out_len, uint64_t n, hipStream_t stream);
 }
@@ -100,6 +102,22 @@ int fdh_device_count(void) {
 }
 
 uint64_t fdh_ultrafast_bound(uint64_t len) { return 53 + (5 + 12 * len + 12 + 7) / 8 + 4; }
+
+uint64_t fdh_stored_size(uint64_t len) {
+    const uint64_t nb = len / 65535, rem = len - nb * 65535;
+    return 2 + nb * (5 + 65535) + (rem ? 5 + rem : 2) + 4;
+}
+
+int fdh_deflate_stored_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                             uint32_t* out_len, uint64_t n, void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    if (!in_off || !out_off || !out_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
+    if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many buffers in one call (max 2^31-1)");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    int rc = fdh_launch_deflate_stored(in, in_off, out, out_off, out_len, n, static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "stored-encoder kernel launch");
+    return FDH_SUCCESS;
+}
 
 int fdh_inflate_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                       uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
@@ -187,11 +205,11 @@ int fdh_decompress_to_vec(const uint8_t* input, size_t input_len, uint8_t** outp
     }
 }
 
-int fdh_compress_to_vec_ultra_fast(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+static int compress_one(bool stored, const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
     if (!output || !output_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null result pointer");
     if (input_len >= 0xFFFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "buffer too large (>= 4 GiB)");
     if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
-    size_t cap = (size_t)fdh_ultrafast_bound(input_len);
+    size_t cap = (size_t)(stored ? fdh_stored_size(input_len) : fdh_ultrafast_bound(input_len));
     DevBuf d_in, d_out, d_meta;
     HIP_TRY(d_in.alloc(input_len));
     HIP_TRY(d_out.alloc(cap));
@@ -201,17 +219,26 @@ int fdh_compress_to_vec_ultra_fast(const uint8_t* input, size_t input_len, uint8
     HIP_TRY(hipMemcpy(d_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
     uint64_t* m = d_meta.as<uint64_t>();
     uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
-    int rc = fdh_deflate_ultrafast_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr);
+    int rc = stored ? fdh_deflate_stored_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr)
+                    : fdh_deflate_ultrafast_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr);
     if (rc != FDH_SUCCESS) return rc;
     HIP_TRY(hipDeviceSynchronize());
     uint32_t n32 = 0;
     HIP_TRY(hipMemcpy(&n32, res, 4, hipMemcpyDeviceToHost));
-    if (n32 == 0xFFFFFFFFu) return fail(FDH_ERR_HIP, "internal: ultra-fast bound exceeded");
+    if (n32 == 0xFFFFFFFFu) return fail(FDH_ERR_HIP, "internal: encoder bound exceeded");
     *output = static_cast<uint8_t*>(std::malloc(n32 ? n32 : 1));
     if (!*output) return fail(FDH_ERR_OUT_OF_MEMORY, "malloc");
     HIP_TRY(hipMemcpy(*output, d_out.p, n32, hipMemcpyDeviceToHost));
     *output_len = n32;
     return FDH_SUCCESS;
+}
+
+int fdh_compress_to_vec_ultra_fast(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+    return compress_one(false, input, input_len, output, output_len);
+}
+
+int fdh_compress_to_vec_stored(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+    return compress_one(true, input, input_len, output, output_len);
 }
 
 void fdh_free(void* p) { std::free(p); }

@@ -111,6 +111,19 @@ int fdh_deflate_ultrafast_batch(const uint8_t *in, const uint64_t *in_off, uint8
 /* Worst-case size of an ultra-fast stream: 53 header bytes + ceil((5 + 12*len + 12)/8) + 4. */
 uint64_t fdh_ultrafast_bound(uint64_t len);
 
+/*
+ * fdh_deflate_stored_batch -- level 0: `compress_to_vec_with_level(input, 0)`
+ * (src/compress/mod.rs:299-303; `Compressor::new(.., 0, true)` :69-71, stored blocks :234-268,
+ * finish :194-214), bit-exact: header 78 01, stored blocks of <= 65535 bytes, an empty fixed block
+ * when the length is a multiple of 65535 (incl. 0), Adler-32.  Same argument convention as
+ * fdh_deflate_ultrafast_batch; slots of at least fdh_stored_size(len_i) bytes.
+ */
+int fdh_deflate_stored_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
+                             const uint64_t *out_off, uint32_t *out_len, uint64_t n,
+                             void *hip_stream);
+/* Exact size of the level-0 stream of a `len`-byte buffer. */
+uint64_t fdh_stored_size(uint64_t len);
+
 /* ---- single-buffer conveniences on HOST memory (names mirror src/lib.rs:29-36) ---------
  * Each stages through the device (H2D, batch of one, D2H) and synchronises.  Results are
  * malloc'd; release with fdh_free().  `*stream_status` receives the per-stream status. */
@@ -121,6 +134,8 @@ int fdh_decompress_to_vec_bounded(const uint8_t *input, size_t input_len, size_t
                                   uint32_t *stream_status); /* decompress.rs:1111 */
 int fdh_compress_to_vec_ultra_fast(const uint8_t *input, size_t input_len, uint8_t **output,
                                    size_t *output_len); /* compress/mod.rs:313 */
+int fdh_compress_to_vec_stored(const uint8_t *input, size_t input_len, uint8_t **output,
+                               size_t *output_len); /* compress_to_vec_with_level(.., 0), compress/mod.rs:299 */
 void fdh_free(void *p);
 
 /* ---- introspection ------------------------------------------------------------------- */

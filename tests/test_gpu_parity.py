@@ -368,6 +368,46 @@ def test_ultrafast_encode_bit_exact(harness):
     assert fd.compress_to_vec_ultra_fast(b"Hello world!") == ob.compress_ultra_fast(b"Hello world!")
 
 
+def test_stored_encode_bit_exact(harness):
+    """Level 0 (compress_to_vec_with_level(.., 0)): bit-exact with the oracle's restatement for the
+    block-boundary sizes, the batch and the host entry points, and it decodes back."""
+    import torch
+    import fdeflate_amd as fd
+    r = np.random.default_rng(11)
+    sizes = [0, 1, 7, 8, 9, 4096, 65534, 65535, 65536, 65535 * 2 - 1, 65535 * 2, 65535 * 2 + 1, 200003]
+    raws = [r.integers(0, 256, n, dtype=np.uint8).tobytes() for n in sizes]
+    want = [ob.compress_stored(x) for x in raws]
+    assert want[0] == bytes.fromhex("7801030000000001")  # the reference's empty-input KAT (level 0 = level 1 here)
+    for x, w in zip(raws, want):
+        assert fd.stored_size(len(x)) == len(w)
+    for x, w in zip(raws[:6], want[:6]):
+        assert fd.compress_to_vec_stored(x) == w
+    # batch, unaligned packing, guard bytes between the slots
+    buf, in_off = streams.pack_exact(raws)
+    caps = [fd.stored_size(len(x)) + 3 for x in raws]
+    out_off = np.zeros(len(raws) + 1, dtype=np.int64)
+    out_off[1:] = np.cumsum(caps)
+    d_out = torch.full((int(out_off[-1]),), 0x5A, dtype=torch.uint8, device="cuda")
+    ln = fd.deflate_stored_batch(torch.as_tensor(buf).cuda(), torch.as_tensor(in_off.astype(np.int64)).cuda(), d_out,
+                                 torch.as_tensor(out_off).cuda())
+    torch.cuda.synchronize()
+    h = d_out.cpu().numpy()
+    for i, w in enumerate(want):
+        o0 = int(out_off[i])
+        assert int(ln[i]) == len(w), (sizes[i], int(ln[i]), len(w))
+        assert h[o0:o0 + len(w)].tobytes() == w, sizes[i]
+        assert np.all(h[o0 + len(w):int(out_off[i + 1])] == 0x5A), sizes[i]
+    # too small a slot is refused, nothing else is touched
+    small = torch.full((10,), 0x5A, dtype=torch.uint8, device="cuda")
+    ln = fd.deflate_stored_batch(torch.as_tensor(np.frombuffer(raws[3], dtype=np.uint8).copy()).cuda(),
+                                 torch.tensor([0, 8], dtype=torch.int64, device="cuda"), small,
+                                 torch.tensor([0, 10], dtype=torch.int64, device="cuda"))
+    assert int(ln[0]) == -1 or int(ln[0]) == 0xFFFFFFFF
+    # and the decoder takes them (stored blocks through the general kernels)
+    names = ["stored%d" % n for n in sizes]
+    harness.assert_inflate_parity(names, want, [len(x) for x in raws])
+
+
 def test_host_api_mirror(harness):
     import fdeflate_amd as fd
     data = b"Hello world! " * 100
