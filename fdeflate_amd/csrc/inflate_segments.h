@@ -2,15 +2,16 @@
 //
 // A stream that starts with the ultra-fast encoder's fixed prefix (reference
 // src/compress/ultrafast.rs:82-88) is one final dynamic block with a known table.  Its block
-// data is cut into 64 equal bit ranges ("segments"), one per lane, and every lane runs the
-// reference's inner loop (src/decompress.rs:645-830: table look-up, 1-2 literals per step, dist-1
-// run) sequentially over its own segment:
+// data is cut into up to 64 equal bit ranges ("segments", >= kSegMinBits each; short streams use
+// fewer lanes), one per lane, and every lane runs the reference's inner loop
+// (src/decompress.rs:645-830: table look-up, 1-2 literals per step, dist-1 run) sequentially over
+// its own segment:
 //
 //   pass 1  every lane decodes from the FIRST BIT of its segment -- a guess, the real symbol
-//           boundary lies up to 17 bits further -- skipping the first kSegWindow bits and then
-//           counting output bytes to the end of the segment.  Huffman codes self-synchronise, so
-//           by the end of the window the guessed chain has (almost always) joined the real one;
-//           x0 = where the chain left the window, end = where it left the segment.
+//           boundary lies up to 17 bits further: the first kSegWindow bits are only walked
+//           (impossible tokens slide on by one bit), then output bytes are counted to the end of
+//           the segment.  Huffman codes self-synchronise, so by the end of the window the guessed
+//           chain has (almost always) joined the real one; x0 = where the chain left the window.
 //   check   lane i takes its real start from lane i-1's end, decodes the window from there
 //           (counting) and must land exactly on x0.  If it does, by induction from lane 0 every
 //           chain from x0 on was the real one.  A lane that lands elsewhere re-counts its segment
@@ -19,11 +20,15 @@
 //           the byte a leading run repeats comes from the nearest lane to the left that emitted
 //           a literal.
 //   pass 2  every lane decodes its real chain again and streams the bytes through a 4-byte
-//           accumulator and a small LDS ring to 16-B aligned global stores, folding them into a
-//           per-lane Adler-32 partial; the partials are combined with the block-combine identity.
+//           accumulator and a 64-B LDS ring to global memory (32-B aligned pairs of 16-B stores;
+//           long runs line by line), folding them into a per-lane Adler-32 partial; the partials
+//           are combined with the block-combine identity.
 //
-// Input is read per lane through a small LDS ring that is topped up by 16-B global loads at
-// wavefront-uniform "events" (two events ahead), so the hot loop never waits on memory.
+// Input is read per lane through a 64-B LDS ring that is topped up at wavefront-uniform "events"
+// (one per kSegSteps steps, two adjacent 16-B loads at a time, committed an event later), so the
+// hot loops never wait on memory.  The hot loops themselves are hand-scheduled groups of
+// literal-only steps (seg_count_group / seg_write_group); any other entry is handled by a
+// select-only C++ step.
 // Anything unusual -- not canonical, a bad / truncated token, a full slot, a checksum
 // mismatch -- leaves the stream PENDING for the exact wave-per-stream kernels.
 #pragma once
