@@ -1,18 +1,18 @@
 // inflate.hip -- batched zlib decode kernels (gfx950).  One independent stream per wavefront.
 //
-// Two kernels share the per-stream decoder of inflate_stream.h:
+// fdh_launch_inflate runs, back to back on the caller's stream (each kernel finishes what it can
+// and leaves the rest PENDING in the status word):
 //
-//   inflate_canon_kernel    8 wavefronts (= 8 streams) per workgroup.  Streams that start with
-//                           the ultra-fast encoder's fixed 53-byte + 5-bit prefix (reference
-//                           src/compress/ultrafast.rs:82-88: zlib header + one final dynamic
-//                           block header) all use the same Huffman tables, so the workgroup
-//                           stages ONE copy of them in LDS (built once per device from those
-//                           header bytes by canon_build_kernel) and each wavefront only needs
-//                           its 7 KiB of input/output staging: 16 wavefronts per CU.
-//                           Every other stream is marked PENDING.
-//   inflate_general_kernel  1 wavefront per workgroup with private tables in LDS: any zlib
-//                           stream (stored / fixed / dynamic blocks, multi-block).  Runs over
-//                           the PENDING streams only when it follows the canon kernel.
+//   inflate_segments_kernel      streams that start with the ultra-fast encoder's fixed 53-byte +
+//                                5-bit prefix (reference src/compress/ultrafast.rs:82-88: zlib header
+//                                + one final dynamic block header): segment-parallel, one shared
+//                                table copy per workgroup (inflate_segments.h).
+//   inflate_canon_kernel         canonical streams the segment kernel left over: 8 wavefronts per
+//                                workgroup sharing ONE copy of the tables (built once per device from
+//                                the prefix bytes by canon_build_kernel), tile + serial decoders.
+//   inflate_general_fast_kernel  any zlib stream (stored / fixed / dynamic, multi-block), private
+//                                10-bit tables: 8 workgroups per CU; leaves exactness-guard cases.
+//   inflate_general_kernel       the same with the reference's 12-bit tables; runs what is left.
 //
 // Exactness guard: results other than Ok that depend on how literals were paired by the
 // double-literal table at the very end of a truncated input, and all hard errors, are re-derived
