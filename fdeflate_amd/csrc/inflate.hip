@@ -17,6 +17,7 @@
 // Exactness guard: results other than Ok that depend on how literals were paired by the
 // double-literal table at the very end of a truncated input, and all hard errors, are re-derived
 // by the symbol-serial decoder, whose pairing is the reference's (DESIGN.md "error parity").
+#include <algorithm>
 #include "inflate_stream.h"
 #include "inflate_lanes.h"
 #include "inflate_segments.h"
@@ -291,7 +292,20 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
         }
     }
     __syncthreads();
-    segments_decode(a, lds);
+    if (a.list) {
+        // persistent wavefronts: every wavefront keeps fetching the next stream, so a short stream
+        // does not leave its slot of the workgroup idle and the table is staged once per workgroup
+        const int lane = threadIdx.x & (kWave - 1);
+        for (uint64_t it = 0; it <= a.n; it++) {  // (bounded: a wavefront can never be handed more than n streams)
+            uint32_t next = 0;
+            if (lane == 0) next = atomicAdd(&a.list[1], 1u);
+            next = uni(next);
+            if (next >= a.n) break;
+            segments_decode(a, lds, next);
+        }
+    } else {
+        segments_decode(a, lds, (uint64_t)blockIdx.x * kSegWaves + threadIdx.x / kWave);
+    }
 }
 
 // Parses the canonical prefix once per device and keeps the resulting tables in g_canon.
@@ -452,6 +466,15 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->hdr,
                         fdh::kCanonBits, fdh::kPending, list};
         unsigned sblocks = (unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves);
+        if (list) {  // persistent wavefronts: two workgroups (80 KiB of LDS each) per CU
+            static int cus[64] = {};
+            if (cus[ordinal & 63] == 0) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ordinal) != hipSuccess || v <= 0) v = 256;
+                cus[ordinal & 63] = v;
+            }
+            sblocks = std::min(sblocks, (unsigned)(2 * cus[ordinal & 63]));
+        }
         hipLaunchKernelGGL(fdh::inflate_segments_kernel, dim3(sblocks), dim3(fdh::kSegWaves * fdh::kWave), 0, stream, sa);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

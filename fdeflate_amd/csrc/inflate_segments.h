@@ -52,10 +52,11 @@ constexpr int kSegWaves = 8;      // wavefronts (= streams) per workgroup: 80 Ki
 constexpr int kSegInWords = 16;   // per-lane input ring, dwords
 constexpr int kSegOutWords = 16;  // per-lane output ring, dwords
 constexpr int kSegChunk = 4;       // dwords per global load of a lane (16 B)
-constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation
+constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation (the default)
+constexpr int kSegWindowShort = 192;  // ... for streams of short codes
 constexpr int kSegSteps = kSegInWords / 2;  // table look-ups between two global-memory events
 constexpr uint32_t kSegNeed = (kSegSteps * 18 + 31) / 32;  // dwords a group of steps can consume (18 bits/token)
-constexpr uint32_t kSegMinBits = 4 * kSegWindow;  // aim: no segment shorter than this (fewer lanes are used instead)
+constexpr uint32_t kSegMinBits = 768;   // aim: no segment shorter than this (fewer lanes are used instead)
 constexpr uint32_t kSegBulkFill = 64;             // runs at least this long are stored line by line
 constexpr uint32_t kNoByte = 0x100;  // "no literal seen yet"
 
@@ -110,7 +111,8 @@ struct SegArgs {
     const uint32_t* canon_hdr;  // 14 dwords of prefix (last one masked)
     uint32_t canon_bits;
     uint32_t pending;
-    uint32_t* list;  // nullable: [0] = count, [4..] = ids of the streams left PENDING (compacted)
+    uint32_t* list;  // nullable: [0] = count, [4..] = ids of the streams left PENDING (compacted);
+                     // [1] = next stream to hand out (persistent wavefronts fetch their work here)
 };
 
 // Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).
@@ -292,7 +294,7 @@ struct SegScan {
     uint32_t eob_bits;
 };
 
-// Walks a chain through the synchronisation window: from s.pos until pos >= kSegWindow (or a stop).
+// Walks a chain through the synchronisation window: from s.pos until pos >= window (or a stop).
 // GUESS: the chain is only a way to find a synchronisation point -- nothing is counted, and an
 // impossible token (or a stray end-of-block) just means "not synchronised yet": slide on by one
 // bit.  The landing check is what guarantees correctness.  Otherwise (the real chain) every byte
@@ -302,8 +304,8 @@ struct SegScan {
 // table in global memory: this happens two or three times per scan).
 template <bool GUESS>
 __device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, const uint32_t* canon_lit, SegReader& rd,
-                                                    uint32_t limit, bool active, SegScan& s) {
-    bool running = active && s.pos < (uint32_t)kSegWindow;
+                                                    uint32_t limit, bool active, uint32_t window, SegScan& s) {
+    bool running = active && s.pos < window;
     uint32_t iter = 0;
     while (__any(running)) {
         rd.events(running);
@@ -324,7 +326,7 @@ __device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, const u
                 bad = bad || (is_run && r.bad_dist);
             }
             uint32_t e_lit = e;
-            const bool single = n8 == 16 && s.pos + 24 >= (uint32_t)kSegWindow;
+            const bool single = n8 == 16 && s.pos + 24 >= window;
             if (__any(running && single)) {
                 if (running && single) {
                     used = canon_lit[win & (kLitSize - 1)] >> 24;  // K_LIT2: bits of the first symbol (inflate_tables.h)
@@ -350,7 +352,7 @@ __device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, const u
             const uint32_t adv = step ? used : 0u;
             s.pos += adv;
             rd.advance(adv, nw);
-            running = step && s.pos < (uint32_t)kSegWindow;
+            running = step && s.pos < window;
         }
     }
     return iter;
@@ -551,10 +553,9 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
     return iter;
 }
 
-__device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
+__device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L, const uint64_t sid) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x / kWave;
-    const uint64_t sid = (uint64_t)blockIdx.x * kSegWaves + wid;
     if (sid >= a.n) return;
     const uint32_t* lit = L.lit;
     const uint32_t lane_off = (uint32_t)wid * (kSegInWords * kWave) + (uint32_t)lane;  // ring slot of word 0
@@ -590,6 +591,10 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     // ---- segments: equal bit ranges of the block data (the trailer bits ride along), one per lane;
     //      short streams use fewer lanes so that a segment stays several windows long ----
     const uint32_t data_bits = in_bits - a.canon_bits;
+    // Synchronisation window: chains of short codes (many tokens per bit) join sooner.  The slot
+    // size stands in for the output length: <= 4.25 stream bits per output byte -> the short window.
+    // (A wrong guess only costs time: lanes that do not land re-count.)
+    const uint32_t window = (uint64_t)in_bits * 4 <= (uint64_t)cap * 17 ? (uint32_t)kSegWindowShort : (uint32_t)kSegWindow;
     const uint32_t nseg = min((uint32_t)kWave, max(1u, (data_bits + kSegMinBits - 1) / kSegMinBits));
     const uint32_t seg = (data_bits + nseg - 1) / nseg;
     const uint32_t seg_bit0 = a.canon_bits + (uint32_t)lane * seg;  // first bit of this lane's segment
@@ -617,7 +622,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
     SEGTIME(0);
     if (in_range) rd.start(in, seg_bit0);
     {
-        uint32_t itw = seg_window_scan<true>(lit, a.canon_lit, rd, limit, in_range, tail);
+        uint32_t itw = seg_window_scan<true>(lit, a.canon_lit, rd, limit, in_range, window, tail);
         (void)itw;
         SEGDBG(6, itw);
         SEGDBG(1, 0);
@@ -658,7 +663,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L) {
             rd.start(in, seg_bit0 + start);
         }
         {
-            uint32_t ith = seg_window_scan<false>(lit, a.canon_lit, rd, limit, need, head);
+            uint32_t ith = seg_window_scan<false>(lit, a.canon_lit, rd, limit, need, window, head);
             (void)ith;
             SEGDBG_ADD(1, ith);
             SEGDBG_ADD(3, 1);
