@@ -553,18 +553,28 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
     return iter;
 }
 
-__device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L, const uint64_t sid) {
+// What pass 2 needs from pass 1 (per lane unless noted).
+struct SegPlan {
+    uint32_t start;   // real chain start of the lane (segment-relative bit)
+    uint32_t end2;    // chain end (>= segment length) or the end-of-block position; 0 = lane has nothing to do
+    uint32_t obase;   // output offset of the lane's first byte
+    uint32_t count;   // output bytes of the lane
+    uint32_t last_e;  // entry of the last literal token in front of the lane (0: none)
+    uint32_t total;   // uniform: output bytes of the stream
+    uint32_t tb;      // uniform: stream byte position of the Adler-32 trailer
+};
+constexpr uint32_t kSegPlanWords = 5 * kWave + 4;  // per stream in global scratch: 5 lane arrays + {ok, total, tb, -}
+
+// Passes 1 + check + scan of one stream.  False: the stream was left PENDING (or is out of range).
+__device__ __forceinline__ bool segments_plan(const SegArgs& a, const uint32_t* lit, uint32_t* in_ring, const uint32_t lane_off,
+                                              const uint64_t sid, SegPlan& plan) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int wid = threadIdx.x / kWave;
-    if (sid >= a.n) return;
-    const uint32_t* lit = L.lit;
-    const uint32_t lane_off = (uint32_t)wid * (kSegInWords * kWave) + (uint32_t)lane;  // ring slot of word 0
+    if (sid >= a.n) return false;
 
     // ---- stream set-up (uniform) ----
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
     const uint64_t o0 = a.out_off[sid], o1 = a.out_off[sid + 1];
     const uint8_t* in = a.in + i0;
-    uint8_t* op = a.out + o0;
     const uint8_t* buf_hi = a.in + a.in_off[a.n];
     const uint64_t ilen = i1 - i0, ocap = o1 - o0;
     bool ours = ilen < (1ull << 28) && ocap < (1ull << 31) &&
@@ -583,10 +593,10 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L, con
         }
         ours = !__any(mismatch);
     }
-    ours = ours && lds_offset(L.lit) == 0;  // the hand-scheduled loops address the table from LDS offset 0
+    ours = ours && lds_offset(lit) == 0;  // the hand-scheduled loops address the table from LDS offset 0
     if (!ours) {
         if (lane == 0) seg_leave_pending(a, sid);
-        return;
+        return false;
     }
     // ---- segments: equal bit ranges of the block data (the trailer bits ride along), one per lane;
     //      short streams use fewer lanes so that a segment stays several windows long ----
@@ -602,7 +612,7 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L, con
     const uint32_t limit = in_range ? in_bits - seg_bit0 : 0;       // tokens must end at or before this
 
     SegReader rd;
-    rd.ring = L.in_ring;
+    rd.ring = in_ring;
     rd.lane_off = lane_off;
     rd.buf_lo = a.in;
     rd.buf_hi = buf_hi;
@@ -732,13 +742,51 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L, con
     SEGDBG(9, total);
     if (!ok) {
         if (lane == 0) seg_leave_pending(a, sid);
-        return;
+        return false;
     }
+
+    plan.start = start;
+    plan.end2 = live ? tail.pos : 0u;
+    plan.obase = obase;
+    plan.count = count;
+    plan.last_e = last_e;
+    plan.total = total;
+    plan.tb = tb;
+    return true;
+}
+
+// Pass 2 of one stream (plan from segments_plan): decode the real chains again, this time writing.
+__device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, const uint64_t sid, const SegPlan& plan) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x / kWave;
+    const uint32_t* lit = L.lit;
+    const uint32_t lane_off = (uint32_t)wid * (kSegInWords * kWave) + (uint32_t)lane;  // ring slot of word 0
+    const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
+    const uint8_t* in = a.in + i0;
+    uint8_t* op = a.out + a.out_off[sid];
+    const uint32_t in_bits = (uint32_t)((i1 - i0) * 8);
+    const uint32_t data_bits = in_bits - a.canon_bits;
+    const uint32_t nseg = min((uint32_t)kWave, max(1u, (data_bits + kSegMinBits - 1) / kSegMinBits));
+    const uint32_t seg = (data_bits + nseg - 1) / nseg;
+    const uint32_t seg_bit0 = a.canon_bits + (uint32_t)lane * seg;
+    const uint32_t start = plan.start, obase = plan.obase, count = plan.count, total = plan.total, tb = plan.tb;
+    uint32_t last_e = plan.last_e;
+    const bool live = plan.end2 != 0 || count != 0;
+    SegReader rd;
+    rd.ring = L.in_ring;
+    rd.lane_off = lane_off;
+    rd.buf_lo = a.in;
+    rd.buf_hi = a.in + a.in_off[a.n];
+    rd.gp = in;
+    rd.in_wr = rd.in_rd = 0;
+    rd.lo = rd.hi = rd.boff = 0;
+    for (int k = 0; k < kSegChunk; k++) rd.pend_a.w[k] = rd.pend_b.w[k] = 0;
+    rd.has_a = rd.has_b = false;
 
     // ---- pass 2: decode the real chain again, this time writing ----
     // Every token on the chain was validated by pass 1 / the check, so nothing is re-checked here
     // except what pass 1 cannot know: a run with nothing before it.
-    uint32_t end2 = live ? tail.pos : 0u;  // chain end (>= seg) or the end-of-block position; 0 = halted
+    uint32_t end2 = plan.end2;  // chain end (>= seg) or the end-of-block position; 0 = halted
     uint32_t pos = start;
     // bytes in front of this lane's first byte in its 16-B line of global memory (the slot itself may
     // start anywhere; the first and the last line of a lane are stored byte by byte)
@@ -975,6 +1023,13 @@ __device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L, con
             seg_leave_pending(a, sid);  // the exact kernels report WrongChecksum
         }
     }
+}
+
+// Both halves on one stream (the fused kernel).
+__device__ __forceinline__ void segments_decode(const SegArgs& a, SegLds& L, const uint64_t sid) {
+    const uint32_t lane_off = (threadIdx.x / kWave) * (uint32_t)(kSegInWords * kWave) + (threadIdx.x & (kWave - 1));
+    SegPlan plan;
+    if (segments_plan(a, L.lit, L.in_ring, lane_off, sid, plan)) segments_write(a, L, sid, plan);
 }
 
 }  // namespace fdh
