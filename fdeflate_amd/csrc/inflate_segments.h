@@ -263,9 +263,9 @@ struct SegReader {
     }
     // One event per kSegSteps steps keeps up with a chunk per group; a group can consume up to
     // kSegSteps * 18 bits = kSegNeed dwords, so denser stretches get extra (waiting) events.
-    __device__ __forceinline__ void events(bool running) {
+    __device__ __forceinline__ void events(bool running, uint32_t need = kSegNeed) {
         event(running);
-        for (int x = 0; x < 2 && __any(running && level() < kSegNeed); x++) event(running);
+        for (int x = 0; x < 2 && __any(running && level() < need); x++) event(running);
     }
 };
 
@@ -515,7 +515,10 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
     const uint32_t ring_base = lds_offset(rd.ring) + 4 * rd.lane_off;
     if (s.pos < lim) rd.refill_now();
     while (__any(s.pos < lim)) {
-        rd.events(s.pos < lim);
+        // nothing is drained in this pass, so one memory event serves two groups of steps (a pair of
+        // chunks = 8 dwords per event covers the <= 2 * kSegNeed - 1 dwords they can consume)
+        rd.events(s.pos < lim, 2 * kSegNeed - 1);
+      for (int half = 0; half < 2; half++) {
         uint32_t gsum = 0;  // sum of the literal entries of this group: byte 1 = 8 x bytes (<= 8 x 16)
         uint32_t left = kSegSteps;
         while (left) {
@@ -545,6 +548,7 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
         }
         s.count8 += (gsum >> 8) & 0xFF;
         iter += kSegSteps;
+      }
         // the fast path checks neither of these per step; both are monotone within a group
         const bool over = active && s.stop == 0 && (s.pos > limit || rd.starved());
         s.stop = over ? 2u : s.stop;
