@@ -909,13 +909,16 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     const uint32_t ring_base = lds_offset(L.in_ring) + 4 * lane_off;
     const uint32_t out_base = lds_offset(L.out_ring) + 4 * lane_off;
     // A lane runs while pos < end2 or a run is being filled.
-    // Outer loop = drain + input event; inner loop = kSegSteps steps (<= 4 B each).
+    // Outer loop = input event + two x (drain + kSegSteps steps of <= 4 B each).
     while (__any(pos < end2 || fill != 0)) {
+        // one memory event per two groups of steps (as in the counting pass); the output side is
+        // drained before every group (<= 32 B are produced per group)
+        rd.events(pos < end2 || fill != 0, 2 * kSegNeed - 1);
+      for (int half = 0; half < 2; half++) {
         drain();
         if (__any(fill >= kSegBulkFill)) {
             if (fill >= kSegBulkFill) bulk_fill(seg_lastlit(last_e));
         }
-        rd.events(pos < end2 || fill != 0);
         uint32_t left = kSegSteps;
         iter += kSegSteps;
         while (left) {
@@ -963,6 +966,7 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
                 sh = tot & 31;
             }
         }
+      }
         if (live && rd.starved()) {  // cannot happen (events() keeps the ring ahead); stop rather than decode garbage
             bad2 = true;
             end2 = 0;
