@@ -808,14 +808,17 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     oring[seg_slot(lane_off, 2)] = 0;
     const uint32_t vend = pad + count;          // virtual end
 
-    auto store_piece = [&](uint32_t vs) __attribute__((always_inline)) {  // 16 virtual bytes at vs
+    // 16 virtual bytes at vs: to global memory (unless a neighbour lane has stored them, see drain) and
+    // into the checksum
+    auto store_piece = [&](uint32_t vs, bool stored_already = false) __attribute__((always_inline)) {
         const uint32_t w = vs >> 2;
         uint4 q;
         q.x = oring[seg_slot(lane_off, w + 0)];
         q.y = oring[seg_slot(lane_off, w + 1)];
         q.z = oring[seg_slot(lane_off, w + 2)];
         q.w = oring[seg_slot(lane_off, w + 3)];
-        if (vs >= pad && vs + 16 <= vend) {
+        if (stored_already) {
+        } else if (vs >= pad && vs + 16 <= vend) {
             *reinterpret_cast<uint4*>(line0 + vs) = q;
         } else {  // first / last line of this lane: only its own bytes
             for (uint32_t k = 0; k < 16; k++) {
@@ -855,12 +858,39 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
             const bool single = odd_first && vstored == 0 && avail >= 16;
             const bool pair = !single && avail >= 32;
             if (!__any(single || pair)) break;
+            // An interior pair is stored by two lanes in ONE instruction (lane l and l ^ 1 each write
+            // 16 of the 32 bytes: first the pairs of the even lanes, then those of the odd lanes), so
+            // the memory pipeline sees 32-B requests instead of twice 16 B.
+            const bool coop = pair && vstored >= pad && vstored + 32 <= vend;
+            {
+                uint8_t* const my_ptr = line0 + vstored;
+                const uint32_t my_w = vstored >> 2;
+                const uint32_t p_lo = __shfl_xor((uint32_t)reinterpret_cast<uintptr_t>(my_ptr), 1, kWave);
+                const uint32_t p_hi = __shfl_xor((uint32_t)(reinterpret_cast<uintptr_t>(my_ptr) >> 32), 1, kWave);
+                const uint32_t p_w = __shfl_xor(my_w, 1, kWave);
+                const bool p_coop = __shfl_xor((int)coop, 1, kWave) != 0;
+                uint8_t* const p_ptr = reinterpret_cast<uint8_t*>(((uintptr_t)p_hi << 32) | p_lo);
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    const bool owner = (lane & 1) == par;
+                    if (owner ? coop : p_coop) {
+                        const uint32_t w = owner ? my_w : p_w + 4;
+                        const uint32_t sl = owner ? lane_off : (lane_off ^ 1u);
+                        uint4 q;
+                        q.x = oring[seg_slot(sl, w + 0)];
+                        q.y = oring[seg_slot(sl, w + 1)];
+                        q.z = oring[seg_slot(sl, w + 2)];
+                        q.w = oring[seg_slot(sl, w + 3)];
+                        *reinterpret_cast<uint4*>(owner ? my_ptr : p_ptr + 16) = q;
+                    }
+                }
+            }
             if (single || pair) {
-                store_piece(vstored);
+                store_piece(vstored, coop);
                 vstored += 16;
             }
             if (pair) {
-                store_piece(vstored);
+                store_piece(vstored, coop);
                 vstored += 16;
             }
         }
