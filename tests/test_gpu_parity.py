@@ -442,6 +442,30 @@ def test_c1_single_4k_stream_plumbing(harness):
     assert fd.decompress_to_vec(comp) == raw
 
 
+def test_mixed_batch_at_scale(harness):
+    """BASELINE config 5 in miniature: a few thousand streams of every kind in ONE batch -- the
+    corpus, stored / fixed / dynamic streams of every zlib strategy, ultra-fast streams, error and
+    mutated streams -- interleaved, with exact / loose / short slots, so that every kernel of the
+    pipeline and its PENDING hand-over (lists, counters) work side by side.  Bit-exact vs the oracle."""
+    pool = []
+    for name, comp, raw in streams.valid_streams():
+        for c in (len(raw), len(raw) + 9, max(len(raw) - 1, 0)):
+            pool.append((name + "@%d" % c, comp, c))
+    for name, comp in streams.corpus_streams():
+        pool.append((name, comp, 1 << 16))
+    for item in streams.error_streams():
+        pool.append(("err_" + item[0], item[1], 4096))
+    for name, comp in streams.mutation_streams(n_per_seed=10, seeds=(7,)):
+        pool.append(("mut_" + name, comp, 70000))
+    r = np.random.default_rng(99)
+    order = r.permutation(len(pool) * 4) % len(pool)   # every stream four times, shuffled
+    names = [pool[i][0] + "#%d" % k for k, i in enumerate(order)]
+    blobs = [pool[i][1] for i in order]
+    caps = [pool[i][2] for i in order]
+    assert len(names) > 1500
+    harness.assert_inflate_parity(names, blobs, caps)
+
+
 def test_batch_roundtrip_at_scale(harness):
     """4096 x 64 KiB: encode on the GPU, decode on the GPU; every stream Ok, lengths exact,
     decoded == raw, and the Adler-32 the decoder reports equals the trailer the encoder wrote
