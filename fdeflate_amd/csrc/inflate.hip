@@ -154,35 +154,24 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
 // double-literal pairing is not the reference's, so every result that needs the exact serial
 // decoder is left PENDING_SERIAL for inflate_general_kernel.
 constexpr int kFastLitBits = 10;
-struct GeneralFastLds {
+#ifndef FDH_FAST_WAVES_PER_SIMD
+#define FDH_FAST_WAVES_PER_SIMD 2
+#endif
+struct GeneralFastLds {  // (no span decoder in this kernel: it would cost LDS for its rings)
     TableSetT<kFastLitBits> tables;
     WaveIo io;
-    uint8_t span_pad[kSpanRingBytes > (int)sizeof(WaveIo) ? kSpanRingBytes - (int)sizeof(WaveIo) : 16];
     HeaderScratch hs;
 };
-__global__ __launch_bounds__(kWave) void inflate_general_fast_kernel(InflateBatchArgs a) {
+__global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_general_fast_kernel(InflateBatchArgs a) {
     __shared__ GeneralFastLds lds;
     const int lane = threadIdx.x;
     const uint64_t sid = blockIdx.x;
     if (sid >= a.n) return;
     if (a.only_pending && a.status[sid] != kPending) return;
     const StreamArgs s = stream_args(a, sid);
-    InflaterT<kFastLitBits> inf(lds.tables, lds.io, &lds.hs, lane);
-    uint32_t slot = kSpanSlots;
-    if (a.span_pool && (a.flags & 0x100u) && s.in_len >= 4096) {
-        if (lane == 0) {
-            slot = (uint32_t)(sid % kSpanSlots);
-            while (atomicCAS(&a.span_pool[slot], 0u, 1u) != 0u) slot = (slot + 1) % kSpanSlots;
-        }
-        slot = uni(slot);
-        inf.span_list = a.span_pool + kSpanSlots + (size_t)slot * (2 * kSpanMaxMatches);
-    }
+    InflaterT<kFastLitBits, false> inf(lds.tables, lds.io, &lds.hs, lane);
     inf.init(s);
     const StreamResult r = inf.run<true, false>();
-    if (slot < kSpanSlots) {
-        __threadfence();
-        if (lane == 0) atomicExch(&a.span_pool[slot], 0u);
-    }
     if (lane == 0) {
         if (needs_serial_recheck(r, a.flags)) {
             a.status[sid] = kPendingSerial;

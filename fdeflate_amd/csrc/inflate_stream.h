@@ -150,7 +150,7 @@ __device__ __forceinline__ FlushState flush_ring(WaveIo* iop, uint8_t* out_al, u
 // LB = index bits of the literal/length table.  12 reproduces the reference's tables (and its
 // double-literal pairing, which the exact serial decoder relies on); the fast general kernel uses
 // a smaller table for occupancy and resolves longer codes by the canonical walk.
-template <int LB>
+template <int LB, bool SPANS = true>
 struct InflaterT {
     static constexpr int kLB = LB;
     static constexpr uint32_t kLSize = 1u << LB;
@@ -1445,7 +1445,7 @@ struct InflaterT {
     template <bool TILES>
     __device__ __forceinline__ uint32_t decode_block_data() {
         for (;;) {
-            if (TILES && span_list && span_credit == 0 && serial_credit == 0 && opos < cap) {
+            if (SPANS && TILES && span_list && span_credit == 0 && serial_credit == 0 && opos < cap) {
                 uint32_t progress;
 #ifdef FDH_DEBUG_TILES
                 const long long ts = clock64();

@@ -70,7 +70,7 @@ enum {
 #define FDH_FLAG_FIRST_ONLY     0x40u /* debug: run only the first kernel of the pipeline */
 #define FDH_FLAG_NO_SEGMENTS    0x80u /* tests/A-B: skip the segment-parallel kernel */
 #define FDH_FLAG_NO_FAST_GENERAL 0x200u /* tests/A-B: skip the small-table general kernel */
-#define FDH_FLAG_SPANS          0x100u /* experimental: segment-parallel "span" decoder inside the general kernel */
+#define FDH_FLAG_SPANS          0x100u /* experimental: segment-parallel "span" decoder inside the 12-bit general kernel */
 
 /*
  * fdh_inflate_batch -- one-shot decode of `n` independent zlib streams, one wavefront each.
