@@ -5,13 +5,27 @@
 
 One "step" = one pass of fdh_inflate_batch over the whole per-GPU batch (65 536 independent
 64 KiB PNG-filter zlib streams in the ultra-fast format, BASELINE config 2), inputs resident in
-HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed / RCCL); streams are
-sharded by rank with no data-path collective, the per-stream metadata is all-gathered inside
-the step, and the step time is the max over ranks.  Prints ONE JSON line on rank 0.
+HBM.  Streams are sharded by rank with no data-path collective; for N > 1 the per-stream metadata
+is all-gathered (RCCL) inside the step and the step time is the max over ranks.
+
+Launching: with N > 1 and no rank environment (WORLD_SIZE unset) this process only starts N rank
+processes (one per GPU, free rendezvous port) and relays rank 0's JSON line -- it never touches
+the GPU itself.  Under an external launcher (torch.distributed.run) every process is a rank.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the headline decode kernel against the HBM peak (live HIP-event time)
+  cpu_baseline  the oracle (C port of the reference) and system zlib timed on the host cores
+  also          (N = 1) the ultra-fast ENCODE of the same buffers (BASELINE config 3) and the
+                decode of zlib level-6 streams of the same data (config 2 (ii)), each with its
+                own roofline object
+  payload_gather_ms  (N > 1) one RCCL all-gather of the decoded payload, timed separately
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,93 +47,255 @@ def parse():
     ap.add_argument("--format", choices=["ultrafast", "zlib6"], default="ultrafast")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-also", action="store_true", help="skip the extra encode / zlib-6 lines")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline leg (4 legs)")
+    ap.add_argument("--zlib6-streams", type=int, default=16384)
+    ap.add_argument("--no-payload-gather", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: run the RCCL metadata gather even with one rank")
     return ap.parse_args()
 
 
-def build_inputs(args, rank, dev):
-    """raw [n, L] on the device and its ultra-fast encoding packed 16-B aligned."""
+# ------------------------------------------------------------------------------------------
+# launcher (parent of the ranks; never initialises the GPU)
+# ------------------------------------------------------------------------------------------
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """Starts n copies of this script as ranks 0..n-1 and relays rank 0's output."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out))
+    rc = 0
+    for p in procs:
+        code = p.wait()
+        if code != 0 and rc == 0:
+            rc = code
+    if rc != 0:
+        for p in procs:   # a failed rank leaves the others waiting at a collective
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------
+# inputs
+# ------------------------------------------------------------------------------------------
+
+def encode_ultrafast(raw, r_off, dev):
+    """raw [n, L] on the device -> its ultra-fast encoding packed 16-B aligned."""
     import torch
     import fdeflate_amd as fd
-    from fdeflate_amd import synth
-    n, L = args.streams, args.stream_bytes
-    raw = synth.gen_batch_torch(rank * n, n, L, device=dev)
-    r_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
-    if args.format == "ultrafast":
-        # pass 1: lengths only (slots of the worst-case bound), pass 2: exact packed layout
-        bound = (fd.ultrafast_bound(L) + 15) & ~15
-        tmp = torch.empty(n * bound, dtype=torch.uint8, device=dev)
-        t_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * bound
-        clen = fd.deflate_ultrafast_batch(raw.view(-1), r_off, tmp, t_off).to(torch.int64)
-        del tmp
-        padded = (clen + 15) & ~15
-        c_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        c_off[1:] = torch.cumsum(padded, 0)
-        comp = torch.zeros(int(c_off[-1]), dtype=torch.uint8, device=dev)
-        clen2 = fd.deflate_ultrafast_batch(raw.view(-1), r_off, comp, c_off).to(torch.int64)
-        assert torch.equal(clen, clen2)
-    else:
-        import zlib
-        import numpy as np
-        h = raw.cpu().numpy()
-        blobs = [zlib.compress(h[i].tobytes(), 6) for i in range(n)]
-        clen_h = np.array([len(b) for b in blobs], dtype=np.int64)
-        off_h = np.zeros(n + 1, dtype=np.int64)
-        off_h[1:] = np.cumsum((clen_h + 15) & ~15)
-        buf = np.zeros(int(off_h[-1]), dtype=np.uint8)
-        for i, b in enumerate(blobs):
-            buf[off_h[i]:off_h[i] + len(b)] = np.frombuffer(b, dtype=np.uint8)
-        comp = torch.from_numpy(buf).to(dev)
-        c_off = torch.from_numpy(off_h).to(dev)
-        clen = torch.from_numpy(clen_h).to(dev)
-    torch.cuda.synchronize()
-    return raw, r_off, comp, c_off, clen
+    n, L = raw.shape
+    # pass 1: lengths only (slots of the worst-case bound), pass 2: exact packed layout
+    bound = (fd.ultrafast_bound(L) + 15) & ~15
+    tmp = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+    t_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * bound
+    clen = fd.deflate_ultrafast_batch(raw.view(-1), r_off, tmp, t_off).to(torch.int64)
+    del tmp
+    padded = (clen + 15) & ~15
+    c_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    c_off[1:] = torch.cumsum(padded, 0)
+    comp = torch.zeros(int(c_off[-1]), dtype=torch.uint8, device=dev)
+    clen2 = fd.deflate_ultrafast_batch(raw.view(-1), r_off, comp, c_off).to(torch.int64)
+    assert torch.equal(clen, clen2)
+    return comp, c_off, clen
 
 
-def cpu_baseline(args, raw, comp, c_off, clen):
-    """The oracle (a port of the reference algorithm) timed on the host cores over a bounded
-    sample of the same workload.  Reported next to the GPU number, never the target."""
+def _z6(b):
+    import zlib
+    return zlib.compress(b, 6)
+
+
+def encode_zlib6(raw_rows, dev):
+    """zlib level 6 (system zlib, host threads: zlib.compress releases the GIL) of the rows of a
+    host array -> packed on the device."""
+    from concurrent.futures import ThreadPoolExecutor
     import numpy as np
-    import oracle_binding as ob
-    cores = os.cpu_count() or 1
-    n = args.streams
-    L = args.stream_bytes
+    import torch
+    n = raw_rows.shape[0]
+    rows = [raw_rows[i].tobytes() for i in range(n)]
+    with ThreadPoolExecutor(max(1, min(64, (os.cpu_count() or 1)))) as pool:
+        blobs = list(pool.map(_z6, rows, chunksize=64))
+    clen_h = np.array([len(b) for b in blobs], dtype=np.int64)
+    off_h = np.zeros(n + 1, dtype=np.int64)
+    off_h[1:] = np.cumsum((clen_h + 15) & ~15)
+    buf = np.zeros(int(off_h[-1]), dtype=np.uint8)
+    for i, b in enumerate(blobs):
+        buf[off_h[i]:off_h[i] + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return torch.from_numpy(buf).to(dev), torch.from_numpy(off_h).to(dev), torch.from_numpy(clen_h).to(dev)
 
-    k = min(n, 4096)                     # bounded sample of the same workload
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline (the oracle as the thing timed: allowed here and only here)
+# ------------------------------------------------------------------------------------------
+
+def build_native_oracle():
+    """A -O3 -march=native build of the oracle for THIS host (the shipped .so is built without
+    -march because it travels between machines).  Called BEFORE the process touches the GPU (it
+    starts gcc as a child process).  Returns the path or None."""
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "fdeflate_oracle.c")
+    try:
+        d = tempfile.mkdtemp(prefix="fdo_native_")
+        so = os.path.join(d, "libfdeflate_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=gnu11", "-pthread", "-shared",
+                               "-o", so, src, "-lz"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return so
+    except Exception:
+        return None
+
+
+def native_oracle(native_so):
+    import ctypes as C
+    import oracle_binding as ob
+    L, how = None, "gcc -O3"
+    if native_so:
+        try:
+            L, how = C.CDLL(native_so), "gcc -O3 -march=native"
+        except OSError:
+            L = None
+    if L is None:
+        L = ob.lib()
+    L.fdo_timed_inflate.restype = C.c_double
+    L.fdo_timed_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                                    C.c_int]
+    return L, how
+
+
+def cpu_baseline(args, comp, c_off, native_so):
+    """The oracle (a port of the reference algorithm) and system zlib timed on the host cores over
+    a bounded sample of the same workload: threads are created once, every thread decodes >= 64
+    streams per pass.  Reported next to the GPU number, never the target."""
+    import ctypes as C
+    import numpy as np
+    cores = os.cpu_count() or 1
+    n, L = args.streams, args.stream_bytes
+    k = min(n, max(4096, 64 * cores))                     # bounded sample of the same workload
     end = int(c_off[k])
-    h_in = comp[:end].cpu().numpy()
-    h_off = c_off[:k + 1].cpu().numpy().astype(np.uint64)
-    out = np.zeros(k * L, dtype=np.uint8)    # touched up front: no page faults inside the timing
-    o_off = (np.arange(k + 1, dtype=np.uint64) * np.uint64(L))
-    ob.inflate_batch(h_in, h_off, out, o_off, False, cores)   # warm-up pass (threads, caches)
-    passes, t_total = 0, 0.0
-    while t_total < args.cpu_seconds and passes < 200:
-        t0 = time.perf_counter()
-        out_len, status, adler = ob.inflate_batch(h_in, h_off, out, o_off, False, cores)
-        t_total += time.perf_counter() - t0
-        passes += 1
-        assert int(status.sum()) == 0 and int(out_len.sum()) == k * L
-    gbs = passes * k * L / t_total / 1e9
-    k2, dt2 = k * passes, t_total
-    return {"value": round(gbs, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": "first %d of the %d streams decoded %d times (%.1f GiB) in %.1f s, "
-                      "oracle/fdo_inflate_batch (C restatement of the reference), %d threads"
-                      % (k, n, passes, k2 * L / 2**30, dt2, cores)}
+    h_in = np.ascontiguousarray(comp[:end].cpu().numpy())
+    h_off = np.ascontiguousarray(c_off[:k + 1].cpu().numpy().astype(np.uint64))
+    out = np.zeros(k * L, dtype=np.uint8)                 # touched up front: no page faults inside the timing
+    o_off = np.arange(k + 1, dtype=np.uint64) * np.uint64(L)
+    lib, how = native_oracle(native_so)
+
+    def timed(threads, kind, k_use):
+        def call(passes):
+            return lib.fdo_timed_inflate(h_in.ctypes.data_as(C.c_void_p), h_off.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), o_off.ctypes.data_as(C.c_void_p),
+                                         k_use, threads, passes, kind)
+        t1 = call(1)                                       # warm-up + calibration pass
+        if t1 <= 0:
+            raise RuntimeError("fdo_timed_inflate failed (%r)" % t1)
+        passes = max(1, min(1000, int(args.cpu_seconds / t1)))
+        t = call(passes)
+        if t <= 0:
+            raise RuntimeError("fdo_timed_inflate failed (%r)" % t)
+        return passes * k_use * L / t / 1e9, passes, t
+
+    k1 = min(k, 1024)                                      # one thread: a smaller slice of the sample
+    all_gbs, all_p, all_t = timed(cores, 0, k)
+    one_gbs, one_p, one_t = timed(1, 0, k1)
+    z_all, _, _ = timed(cores, 1, k)
+    z_one, _, _ = timed(1, 1, k1)
+    return {"value": round(all_gbs, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "value_1_thread": round(one_gbs, 4),
+            "zlib_value": round(z_all, 3), "zlib_value_1_thread": round(z_one, 4),
+            "sample": "first %d of the %d streams, %d passes (%.1f GiB decompressed) in %.1f s on %d persistent "
+                      "threads (>= %d streams per thread per pass); 1 thread: first %d streams x %d passes in %.1f s; "
+                      "oracle/fdo_timed_inflate = C port of the reference algorithm (%s); zlib_* = system zlib "
+                      "uncompress() on the same sample"
+                      % (k, n, all_p, all_p * k * L / 2**30, all_t, cores, k // cores, k1, one_p, one_t, how)}
+
+
+# ------------------------------------------------------------------------------------------
+# timing helpers
+# ------------------------------------------------------------------------------------------
+
+def kernel_source_sha():
+    """Hash of the kernel sources: the PMC traffic figure of profiles/ is only quoted when it was
+    measured on exactly this code."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fdeflate_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(key):
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        tj = json.load(open(tpath))
+        if tj.get("kernel_source_sha") != kernel_source_sha():
+            return None      # measured on other code: not this run's traffic
+        return tj.get(key, {}).get("hbm_bytes_per_step")
+    except Exception:
+        return None
+
+
+def time_steps(step, steps, warmup, barrier):
+    """warmup untimed steps, then `steps` timed ones -> (wall seconds, per-step HIP-event ms)."""
+    import torch
+    for _ in range(warmup):
+        step()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for k in range(steps):
+        step()
+        ev[k + 1].record()
+    barrier()
+    wall = time.perf_counter() - t0
+    return wall, [ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]
+
+
+def roofline(alg_bytes, kern_ms, kernel, traffic):
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel,
+            "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+
+
+DECODE_KERNELS = ("inflate_segments_kernel (+ inflate_canon_kernel / inflate_general_fast_kernel / "
+                  "inflate_general_kernel follow-ups, one fdh_inflate_batch launch)")
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     import fdeflate_amd as fd
     from fdeflate_amd import distributed as fdist
+    from fdeflate_amd import synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "decode" and args.format == "ultrafast"
+    native_so = build_native_oracle() if want_cpu else None   # child process: before any GPU call
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -129,21 +305,29 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n, L = args.streams, args.stream_bytes
-    raw, r_off, comp, c_off, clen = build_inputs(args, rank, dev)
+    raw = synth.gen_batch_torch(rank * n, n, L, device=dev)
+    r_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    if args.format == "ultrafast":
+        comp, c_off, clen = encode_ultrafast(raw, r_off, dev)
+    else:
+        comp, c_off, clen = encode_zlib6(raw.cpu().numpy(), dev)
+    torch.cuda.synchronize()
     out = torch.empty(n * L, dtype=torch.uint8, device=dev)
     out_len = torch.empty(n, dtype=torch.int32, device=dev)
     status = torch.empty(n, dtype=torch.int32, device=dev)
     adler = torch.empty(n, dtype=torch.int32, device=dev)
     bound = (fd.ultrafast_bound(L) + 15) & ~15
-    if args.mode == "encode":
-        enc_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * bound
-        enc_out = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+    enc_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * bound
+    enc_out = None
 
-    def step():
-        if args.mode == "decode":
-            fd.inflate_batch(comp, c_off, out, r_off, out_len, status, adler, flags=args.flags)
-        else:
-            fd.deflate_ultrafast_batch(raw.view(-1), r_off, enc_out, enc_off, out_len)
+    def decode_step():
+        fd.inflate_batch(comp, c_off, out, r_off, out_len, status, adler, flags=args.flags)
+        if use_dist:
+            return fdist.gather_metadata(status, out_len, adler)
+        return None
+
+    def encode_step():
+        fd.deflate_ultrafast_batch(raw.view(-1), r_off, enc_out, enc_off, out_len)
         if use_dist:
             return fdist.gather_metadata(status, out_len, adler)
         return None
@@ -154,52 +338,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # correctness outside the timed region
-    if args.mode == "decode":
+    if args.mode == "encode":
+        enc_out = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+        step = encode_step
+    else:
+        step = decode_step
+        # correctness outside the timed region
+        decode_step()
+        barrier()
         assert int(status.abs().sum()) == 0, "decode reported errors"
         assert bool((out_len == L).all()) and torch.equal(out, raw.view(-1)), "decoded bytes differ"
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    barrier()
-    t0 = time.perf_counter()
-    ev[0].record()
-    for k in range(args.steps):
-        step()
-        ev[k + 1].record()
-    barrier()
-    wall = time.perf_counter() - t0
-    kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+
+    wall, kern_ms = time_steps(step, args.steps, args.warmup, barrier)
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t[0])
 
+    payload_ms = None
+    if world > 1 and args.mode == "decode" and not args.no_payload_gather:
+        # the optional payload gather (every rank receives every shard's decoded bytes): link-bound
+        # over xGMI, reported on its own and never part of `value`
+        try:
+            full = fdist.gather_payload(out)   # warm-up (allocates world x shard)
+            barrier()
+            t0 = time.perf_counter()
+            fdist.gather_payload(out, into=full)
+            barrier()
+            tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            payload_ms = round(float(tp[0]) * 1e3, 3)
+            del full
+        except Exception as e:
+            payload_ms = "failed: %r" % (e,)
+
     in_bytes = int(clen.sum())
     out_bytes = n * L
     ms_per_step = wall * 1e3 / args.steps
     if args.mode == "decode":
-        units = out_bytes          # decompressed bytes
         metric = "decompressed GB/s, batched zlib decode of %d x %d KiB PNG-filter streams per GPU" % (n, L // 1024)
     else:
-        units = out_bytes          # raw input bytes consumed
         metric = "input GB/s, batched ultra-fast zlib encode of %d x %d KiB buffers per GPU" % (n, L // 1024)
-    value = units * world / (wall / args.steps) / 1e9
+    value = out_bytes * world / (wall / args.steps) / 1e9
 
     if rank == 0:
         kern_avg_ms = sum(kern_ms) / len(kern_ms)
         alg = in_bytes + out_bytes + 24 * n    # in_len + out_len + 24 per stream
-        achieved = alg / (kern_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                # the committed PMC passes were taken on the default (ultra-fast format) workload only
-                traffic = tj.get(args.mode, {}).get("hbm_bytes_per_step") if args.format == "ultrafast" else None
-            except Exception:
-                traffic = None
+        traffic = profiled_traffic(args.mode) if args.format == "ultrafast" and n == 65536 else None
         res = {
             "metric": metric, "value": round(value, 3), "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -212,19 +397,64 @@ def main():
                                       in_bytes / n),
                        "streams_per_gpu": n, "stream_bytes": L, "format": args.format, "mode": args.mode,
                        "sharding": "contiguous stream ranges per rank, metadata all_gather per step"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "inflate_segments_kernel (+ inflate_canon_kernel / inflate_general_fast_kernel / inflate_general_kernel follow-ups, one fdh_inflate_batch launch)"
-                         if args.mode == "decode" else "deflate_ultrafast_kernel",
-                         "kernel_ms_avg": round(kern_avg_ms, 4), "algorithmic_bytes_per_launch": alg},
+            "roofline": roofline(alg, kern_avg_ms, DECODE_KERNELS if args.mode == "decode" else "deflate_ultrafast_kernel",
+                                 traffic),
         }
-        if world == 1 and not args.no_cpu_baseline and args.mode == "decode":
+        res["roofline"]["traffic_source"] = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                             "passes of this exact kernel source)" if traffic is not None else None)
+        if payload_ms is not None:
+            res["payload_gather_ms"] = payload_ms
+        also = []
+        if world == 1 and not args.no_also and args.mode == "decode" and args.format == "ultrafast":
+            # BASELINE config 3: ultra-fast encode of the same buffers
             try:
-                res["cpu_baseline"] = cpu_baseline(args, raw, comp, c_off, clen)
+                enc_out = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+                w2, k2 = time_steps(encode_step, args.steps, args.warmup, barrier)
+                elen = out_len.to(torch.int64)
+                assert bool((elen == clen).all()), "encoder lengths changed"
+                k2avg = sum(k2) / len(k2)
+                also.append({"workload": "BASELINE config 3: ultra-fast encode of the same %d x %d KiB buffers" % (n, L // 1024),
+                             "metric": "input GB/s", "value": round(out_bytes / (w2 / args.steps) / 1e9, 3),
+                             "ms_per_step": round(w2 * 1e3 / args.steps, 4),
+                             "roofline": roofline(alg, k2avg, "deflate_ultrafast_kernel", profiled_traffic("encode")
+                                                  if n == 65536 else None)})
+                del enc_out
+            except Exception as e:
+                also.append({"workload": "BASELINE config 3 (encode)", "error": repr(e)})
+            # BASELINE config 2 (ii): the same data as zlib level-6 streams (general kernels)
+            try:
+                nz = min(n, args.zlib6_streams)
+                zcomp, zoff, zlen = encode_zlib6(raw[:nz].cpu().numpy(), dev)
+                zr_off = r_off[:nz + 1]
+                zout = out[:nz * L]
+
+                def z_step():
+                    fd.inflate_batch(zcomp, zoff, zout, zr_off, out_len[:nz], status[:nz], adler[:nz])
+
+                z_step()
+                barrier()
+                assert int(status[:nz].abs().sum()) == 0 and torch.equal(zout, raw[:nz].view(-1)), "zlib-6 decode differs"
+                zsteps = max(3, args.steps // 4)
+                w3, k3 = time_steps(z_step, zsteps, 1, barrier)
+                zalg = int(zlen.sum()) + nz * L + 24 * nz
+                also.append({"workload": "BASELINE config 2 (ii): %d x %d KiB of the same data as zlib level-6 streams "
+                                         "(dynamic blocks, real distances), mean compressed %.0f B/stream"
+                                         % (nz, L // 1024, float(zlen.sum()) / nz),
+                             "metric": "decompressed GB/s", "value": round(nz * L / (w3 / zsteps) / 1e9, 3),
+                             "ms_per_step": round(w3 * 1e3 / zsteps, 4), "steps": zsteps,
+                             "roofline": roofline(zalg, sum(k3) / len(k3),
+                                                  "inflate_general_fast_kernel (+ inflate_general_kernel)", None)})
+            except Exception as e:
+                also.append({"workload": "BASELINE config 2 (ii) (zlib-6 decode)", "error": repr(e)})
+        if also:
+            res["also"] = also
+        if want_cpu:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args, comp, c_off, native_so)
             except Exception as e:  # the baseline is a reported extra, never fatal
                 res["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

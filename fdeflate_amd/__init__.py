@@ -4,14 +4,14 @@ Public surface mirrors image-rs/fdeflate (reference src/lib.rs:29-36) for the ho
 decompress_to_vec, decompress_to_vec_bounded, compress_to_vec_ultra_fast, DecompressionError,
 plus the batched device entry points.  See DESIGN.md / INTEGRATION.md.
 """
-from .api import (DecompressionError, OutputTooLarge, STATUS_NAMES, FLAG_IGNORE_ADLER32,
+from .api import (Decompressor, DecompressionError, OutputTooLarge, STATUS_NAMES, FLAG_IGNORE_ADLER32,
                   FLAG_SERIAL_ONLY, FLAG_GENERAL_ONLY, FLAG_NO_RECHECK, compress_to_vec_ultra_fast, debug_build_tables,
                   decompress_to_vec, decompress_to_vec_bounded, deflate_ultrafast_batch,
                   inflate_batch, ultrafast_bound, compress_to_vec_stored, deflate_stored_batch,
                   stored_size)
 
 __all__ = [
-    "DecompressionError", "OutputTooLarge", "STATUS_NAMES", "FLAG_IGNORE_ADLER32",
+    "Decompressor", "DecompressionError", "OutputTooLarge", "STATUS_NAMES", "FLAG_IGNORE_ADLER32",
     "FLAG_SERIAL_ONLY", "FLAG_GENERAL_ONLY", "FLAG_NO_RECHECK", "compress_to_vec_ultra_fast", "debug_build_tables", "decompress_to_vec",
     "decompress_to_vec_bounded", "deflate_ultrafast_batch", "inflate_batch", "ultrafast_bound",
     "compress_to_vec_stored", "deflate_stored_batch", "stored_size",

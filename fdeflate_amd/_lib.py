@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libfdeflate_hip.so")
+# FDH_LIB: diagnostics only (tools/segdiag.py loads an instrumented build of the same library)
+SO_PATH = os.environ.get("FDH_LIB") or os.path.join(_HERE, "libfdeflate_hip.so")
 
 _lib = None
 
@@ -55,6 +56,16 @@ def lib():
     L.fdh_compress_to_vec_ultra_fast.restype = C.c_int
     L.fdh_compress_to_vec_ultra_fast.argtypes = [vp, sz, pp, C.POINTER(sz)]
     L.fdh_free.argtypes = [vp]
+    L.fdh_decompressor_new.restype = vp
+    L.fdh_decompressor_new.argtypes = []
+    L.fdh_decompressor_free.argtypes = [vp]
+    L.fdh_decompressor_free.restype = None
+    L.fdh_decompressor_ignore_adler32.argtypes = [vp]
+    L.fdh_decompressor_ignore_adler32.restype = None
+    L.fdh_decompressor_is_done.argtypes = [vp]
+    L.fdh_decompressor_is_done.restype = C.c_int
+    L.fdh_decompressor_read.restype = C.c_int
+    L.fdh_decompressor_read.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]
     _lib = L
     return L
 
@@ -64,6 +75,8 @@ EXPORTED_SYMBOLS = [
     "fdh_inflate_batch", "fdh_deflate_ultrafast_batch", "fdh_debug_build_tables",
     "fdh_decompress_to_vec", "fdh_decompress_to_vec_bounded", "fdh_compress_to_vec_ultra_fast",
     "fdh_free", "fdh_stored_size", "fdh_deflate_stored_batch", "fdh_compress_to_vec_stored",
+    "fdh_decompressor_new", "fdh_decompressor_free", "fdh_decompressor_ignore_adler32",
+    "fdh_decompressor_is_done", "fdh_decompressor_read",
 ]
 
 

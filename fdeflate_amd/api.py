@@ -53,6 +53,48 @@ class OutputTooLarge(Exception):
         super().__init__("OutputTooLarge")
 
 
+class Decompressor:
+    """Mirror of fdeflate::Decompressor (src/decompress.rs:96-342) over fdh_decompressor_*:
+
+        d = Decompressor(); d.ignore_adler32()
+        consumed, produced = d.read(input, output, output_position)   # raises DecompressionError
+        d.is_done()
+
+    `output` is a writable buffer (bytearray / numpy uint8 array); bytes are written at
+    output[output_position : output_position + produced]."""
+
+    def __init__(self):
+        self._L = _lib.lib()
+        self._d = self._L.fdh_decompressor_new()
+        if not self._d:
+            raise MemoryError("fdh_decompressor_new")
+
+    def __del__(self):
+        d, self._d = getattr(self, "_d", None), None
+        if d:
+            self._L.fdh_decompressor_free(d)
+
+    def ignore_adler32(self):
+        self._L.fdh_decompressor_ignore_adler32(self._d)
+
+    def is_done(self):
+        return bool(self._L.fdh_decompressor_is_done(self._d))
+
+    def read(self, data, output, output_position):
+        data = bytes(data)
+        mv = memoryview(output)
+        if mv.readonly or mv.itemsize != 1 or not mv.contiguous:
+            raise ValueError("output must be a writable contiguous byte buffer")
+        n = mv.nbytes
+        obuf = (C.c_uint8 * n).from_buffer(mv) if n else None
+        c, p, st = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        _lib.check(self._L.fdh_decompressor_read(self._d, data, len(data), obuf, n, output_position,
+                                                 C.byref(c), C.byref(p), C.byref(st)))
+        if st.value != 0:
+            raise DecompressionError(st.value)
+        return c.value, p.value
+
+
 def _take(ptr, n):
     try:
         return C.string_at(ptr, n) if n else b""
@@ -126,16 +168,37 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _check_dev(*ts):
-    import torch
-    for t in ts:
-        if t is None:
-            continue
-        if not t.is_cuda:
-            raise ValueError("batched entry points take device tensors (HBM resident)")
-        if not t.is_contiguous():
-            raise ValueError("tensors must be contiguous")
-    return torch.cuda.current_stream().cuda_stream
+class _OnDevice:
+    """Checks that every tensor lives on ONE GPU and makes that GPU current for the duration of
+    the call: the C ABI launches on the current device (hipGetDevice) and on the stream it is
+    handed, so both must belong to the tensors' device even when another one is current."""
+
+    def __init__(self, *ts):
+        import torch
+        dev = None
+        for t in ts:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise ValueError("batched entry points take device tensors (HBM resident)")
+            if not t.is_contiguous():
+                raise ValueError("tensors must be contiguous")
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise ValueError("all tensors of one call must live on the same GPU (%s vs %s)" % (dev, t.device))
+        if dev is None:
+            raise ValueError("no tensors")
+        self.dev = dev
+        self._guard = torch.cuda.device(dev)
+
+    def __enter__(self):
+        import torch
+        self._guard.__enter__()
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        return self._guard.__exit__(*exc)
 
 
 def inflate_batch(comp, in_off, out, out_off, out_len=None, status=None, adler=None, flags=0):
@@ -151,10 +214,10 @@ def inflate_batch(comp, in_off, out, out_off, out_len=None, status=None, adler=N
         status = torch.empty(n, dtype=torch.int32, device=dev)
     if adler is None:
         adler = torch.empty(n, dtype=torch.int32, device=dev)
-    stream = _check_dev(comp, in_off, out, out_off, out_len, status, adler)
-    _lib.check(_lib.lib().fdh_inflate_batch(_ptr(comp), _ptr(in_off), _ptr(out), _ptr(out_off),
-                                           _ptr(out_len), _ptr(status), _ptr(adler), n, flags,
-                                           C.c_void_p(stream)))
+    with _OnDevice(comp, in_off, out, out_off, out_len, status, adler) as stream:
+        _lib.check(_lib.lib().fdh_inflate_batch(_ptr(comp), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                               _ptr(out_len), _ptr(status), _ptr(adler), n, flags,
+                                               C.c_void_p(stream)))
     return out_len, status, adler
 
 
@@ -164,9 +227,9 @@ def deflate_ultrafast_batch(raw, in_off, out, out_off, out_len=None):
     n = in_off.numel() - 1
     if out_len is None:
         out_len = torch.empty(n, dtype=torch.int32, device=raw.device)
-    stream = _check_dev(raw, in_off, out, out_off, out_len)
-    _lib.check(_lib.lib().fdh_deflate_ultrafast_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
-                                                     _ptr(out_len), n, C.c_void_p(stream)))
+    with _OnDevice(raw, in_off, out, out_off, out_len) as stream:
+        _lib.check(_lib.lib().fdh_deflate_ultrafast_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                                         _ptr(out_len), n, C.c_void_p(stream)))
     return out_len
 
 
@@ -176,9 +239,9 @@ def deflate_stored_batch(raw, in_off, out, out_off, out_len=None):
     n = in_off.numel() - 1
     if out_len is None:
         out_len = torch.empty(n, dtype=torch.int32, device=raw.device)
-    stream = _check_dev(raw, in_off, out, out_off, out_len)
-    _lib.check(_lib.lib().fdh_deflate_stored_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
-                                                  _ptr(out_len), n, C.c_void_p(stream)))
+    with _OnDevice(raw, in_off, out, out_off, out_len) as stream:
+        _lib.check(_lib.lib().fdh_deflate_stored_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                                      _ptr(out_len), n, C.c_void_p(stream)))
     return out_len
 
 
@@ -189,9 +252,9 @@ def debug_build_tables(code_lengths, hlit):
     lit = torch.empty(4096, dtype=torch.int32, device="cuda")
     dist = torch.empty(512, dtype=torch.int32, device="cuda")
     st = torch.zeros(4, dtype=torch.int32, device="cuda")
-    stream = _check_dev(cl, lit, dist, st)
-    _lib.check(_lib.lib().fdh_debug_build_tables(_ptr(cl), hlit, _ptr(lit), _ptr(dist), _ptr(st),
-                                                C.c_void_p(stream)))
+    with _OnDevice(cl, lit, dist, st) as stream:
+        _lib.check(_lib.lib().fdh_debug_build_tables(_ptr(cl), hlit, _ptr(lit), _ptr(dist), _ptr(st),
+                                                    C.c_void_p(stream)))
     torch.cuda.synchronize()
     s = st.cpu().tolist()
     return s[0], lit.cpu().numpy().view("uint32"), dist.cpu().numpy().view("uint32"), tuple(s[1:])

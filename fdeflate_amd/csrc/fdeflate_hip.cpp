@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +96,9 @@ const char* fdh_status_name(uint32_t s) { return s < 18 ? kStatusNames[s] : "Unk
 
 const char* fdh_last_error(void) { return g_last_error.c_str(); }
 
+// used by the other translation units of the library (not part of the public header)
+void fdh_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+
 int fdh_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -156,53 +160,77 @@ int fdh_debug_build_tables(const uint8_t* code_lengths320, uint32_t hlit, uint32
 
 // ---- single-buffer conveniences (host memory) --------------------------------------------
 
-static int inflate_one(const uint8_t* input, size_t input_len, size_t cap, uint8_t** output, size_t* output_len,
+// One decode of a host buffer into a device slot of `cap` bytes; the decoded (or partial) bytes
+// are returned in a malloc'd buffer.  The device copy of the input is kept by the caller so that
+// a retry with a larger slot does not upload it again.
+static int inflate_one(DevBuf& d_in, size_t input_len, size_t cap, uint8_t** output, size_t* output_len,
                        uint32_t* stream_status) {
-    if (!output || !output_len || !stream_status) return fail(FDH_ERR_INVALID_ARGUMENT, "null result pointer");
-    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
-    if (cap > 0xFFFFFFFFull) cap = 0xFFFFFFFFull;
-    DevBuf d_in, d_out, d_meta;
-    HIP_TRY(d_in.alloc(input_len));
+    DevBuf d_out, d_meta;
     HIP_TRY(d_out.alloc(cap));
     HIP_TRY(d_meta.alloc(64));
     uint64_t meta[8] = {0, (uint64_t)input_len, 0, (uint64_t)cap, 0, 0, 0, 0};
-    if (input_len) HIP_TRY(hipMemcpy(d_in.p, input, input_len, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
     uint64_t* m = d_meta.as<uint64_t>();
     uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
     int rc = fdh_inflate_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, res + 1, res + 2, 1, 0, nullptr);
     if (rc != FDH_SUCCESS) return rc;
-    HIP_TRY(hipDeviceSynchronize());
     uint32_t host_res[4];
-    HIP_TRY(hipMemcpy(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost));  // synchronises the null stream
     *stream_status = host_res[1];
     size_t n = host_res[0];
-    *output = static_cast<uint8_t*>(std::malloc(n ? n : 1));
-    if (!*output) return fail(FDH_ERR_OUT_OF_MEMORY, "malloc");
-    if (n) HIP_TRY(hipMemcpy(*output, d_out.p, n, hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(n ? n : 1));
+    if (!buf) return fail(FDH_ERR_OUT_OF_MEMORY, "malloc");
+    if (n) {
+        hipError_t e = hipMemcpy(buf, d_out.p, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            std::free(buf);
+            return hip_fail(e, "hipMemcpy(decoded bytes)");
+        }
+    }
+    *output = buf;
     *output_len = n;
     return FDH_SUCCESS;
 }
 
-int fdh_decompress_to_vec_bounded(const uint8_t* input, size_t input_len, size_t maxlen, uint8_t** output,
-                                  size_t* output_len, uint32_t* stream_status) {
-    return inflate_one(input, input_len, maxlen, output, output_len, stream_status);
-}
-
-// decompress_to_vec grows its Vec without bound (src/decompress.rs:1079-1087).  The device needs
-// a slot size up front, so the slot starts at 4x the input (>= 64 KiB) and is doubled while the
-// stream reports OutputTooLarge.
-int fdh_decompress_to_vec(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len,
-                          uint32_t* stream_status) {
-    size_t cap = input_len * 4 + 65536;
+// decompress_to_vec_bounded (src/decompress.rs:1111-1144).  The reference grows its Vec from 1 KiB
+// by 32 KiB steps up to `maxlen` (:1117, :1133); the device needs a slot size up front, so the slot
+// starts at min(maxlen, 4 x input + 64 KiB) and is quadrupled (up to maxlen) while the stream
+// reports OutputTooLarge below maxlen -- a huge `maxlen` never allocates more than the stream
+// needs (x4), and the result is the one a slot of `maxlen` bytes would have given.
+static int inflate_growing(const uint8_t* input, size_t input_len, size_t maxlen, uint8_t** output,
+                           size_t* output_len, uint32_t* stream_status) {
+    if (!output || !output_len || !stream_status) return fail(FDH_ERR_INVALID_ARGUMENT, "null result pointer");
+    *output = nullptr;
+    *output_len = 0;
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    if (input_len >= (1ull << 31)) return fail(FDH_ERR_INVALID_ARGUMENT, "stream too large (>= 2 GiB)");
+    if (maxlen > 0xFFFFFFF0ull) maxlen = 0xFFFFFFF0ull;
+    DevBuf d_in;
+    HIP_TRY(d_in.alloc(input_len));
+    if (input_len) HIP_TRY(hipMemcpy(d_in.p, input, input_len, hipMemcpyHostToDevice));
+    size_t cap = std::min<size_t>(maxlen, input_len * 4 + 65536);
     for (;;) {
-        int rc = inflate_one(input, input_len, cap, output, output_len, stream_status);
+        int rc = inflate_one(d_in, input_len, cap, output, output_len, stream_status);
         if (rc != FDH_SUCCESS) return rc;
-        if (*stream_status != FDH_OUTPUT_TOO_LARGE || cap >= 0xFFFFFFFFull) return FDH_SUCCESS;
+        if (*stream_status != FDH_OUTPUT_TOO_LARGE || cap >= maxlen) return FDH_SUCCESS;
         std::free(*output);
         *output = nullptr;
-        cap = cap * 4 > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap * 4;
+        *output_len = 0;
+        cap = cap > maxlen / 4 ? maxlen : cap * 4;
     }
+}
+
+int fdh_decompress_to_vec_bounded(const uint8_t* input, size_t input_len, size_t maxlen, uint8_t** output,
+                                  size_t* output_len, uint32_t* stream_status) {
+    return inflate_growing(input, input_len, maxlen, output, output_len, stream_status);
+}
+
+// decompress_to_vec grows its Vec without bound (src/decompress.rs:1079-1087): the same loop with
+// the ABI's largest slot as the bound.
+int fdh_decompress_to_vec(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len,
+                          uint32_t* stream_status) {
+    return inflate_growing(input, input_len, 0xFFFFFFF0ull, output, output_len, stream_status);
 }
 
 static int compress_one(bool stored, const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
@@ -226,9 +254,16 @@ static int compress_one(bool stored, const uint8_t* input, size_t input_len, uin
     uint32_t n32 = 0;
     HIP_TRY(hipMemcpy(&n32, res, 4, hipMemcpyDeviceToHost));
     if (n32 == 0xFFFFFFFFu) return fail(FDH_ERR_HIP, "internal: encoder bound exceeded");
-    *output = static_cast<uint8_t*>(std::malloc(n32 ? n32 : 1));
-    if (!*output) return fail(FDH_ERR_OUT_OF_MEMORY, "malloc");
-    HIP_TRY(hipMemcpy(*output, d_out.p, n32, hipMemcpyDeviceToHost));
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(n32 ? n32 : 1));
+    if (!buf) return fail(FDH_ERR_OUT_OF_MEMORY, "malloc");
+    if (n32) {
+        hipError_t e = hipMemcpy(buf, d_out.p, n32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            std::free(buf);
+            return hip_fail(e, "hipMemcpy(compressed bytes)");
+        }
+    }
+    *output = buf;
     *output_len = n32;
     return FDH_SUCCESS;
 }

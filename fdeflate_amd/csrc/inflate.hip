@@ -18,6 +18,7 @@
 // double-literal table at the very end of a truncated input, and all hard errors, are re-derived
 // by the symbol-serial decoder, whose pairing is the reference's (DESIGN.md "error parity").
 #include <algorithm>
+#include <mutex>
 #include "inflate_stream.h"
 #include "inflate_lanes.h"
 #include "inflate_segments.h"
@@ -37,6 +38,7 @@ struct CanonTables {
     uint32_t dist[kDistSize];
     uint32_t eof[4];
     uint32_t hdr[16];  // the prefix as little-endian dwords (14 used)
+    uint32_t len4[32]; // code lengths of the literals 0..255, 4 bits each (segment kernel: first literal of a step)
     uint32_t status;   // build status (ST_OK expected)
 };
 __device__ CanonTables g_canon;
@@ -272,14 +274,11 @@ __global__ __launch_bounds__(kLaneBlock) void inflate_lanes_kernel(LaneArgs a) {
 // (inflate_segments.h).
 __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(SegArgs a) {
     __shared__ SegLds lds;
-    {  // stage the canonical table, converted to this kernel's entry layout
-        const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit);
-        uint4* dst = reinterpret_cast<uint4*>(lds.lit);
-        for (int i = threadIdx.x; i < kLitSize / 4; i += kSegWaves * kWave) {
-            const uint4 e = src[i];
-            dst[i] = make_uint4(seg_entry_from(e.x), seg_entry_from(e.y), seg_entry_from(e.z), seg_entry_from(e.w));
-        }
-    }
+    // the hand-scheduled loops address the table from LDS offset 0 (`raw & 0x3ffc` IS the address)
+    if (lds_offset(lds.lit) != 0) __builtin_trap();
+    // stage the table in this kernel's entry layout (up to three literals per entry), built from the
+    // canonical table in global memory (L2 resident after the first workgroups)
+    for (int i = threadIdx.x; i < kLitSize; i += kSegWaves * kWave) lds.lit[i] = seg_entry_build(a.canon_lit, (uint32_t)i);
     __syncthreads();
     if (a.list) {
         // persistent wavefronts: every wavefront keeps fetching the next stream, so a short stream
@@ -321,6 +320,11 @@ __global__ __launch_bounds__(kWave) void canon_build_kernel() {
                      ((uint32_t)g_canon_header[4 * lane + 2] << 16) | ((uint32_t)g_canon_header[4 * lane + 3] << 24);
         if (lane == 13) w &= (1u << (kCanonBits - 13 * 32)) - 1;
         g_canon.hdr[lane] = w;
+    }
+    if (lane < 32) {
+        uint32_t w = 0;
+        for (int j = 0; j < 8; j++) w |= ((uint32_t)lds.hs.lens[8 * lane + j] & 15u) << (4 * j);
+        g_canon.len4[lane] = w;
     }
     if (lane == 0) {
         g_canon.eof[0] = inf.eof_code;
@@ -367,6 +371,11 @@ extern "C" int fdh_debug_read_seg(uint32_t* host) {
     hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segdbg), 64 * 16 * 4);
     return 0;
 }
+extern "C" int fdh_debug_read_seg2(uint32_t* host) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segdbg2), 16 * 16 * 4);
+    return 0;
+}
 extern "C" int fdh_debug_read_gstat(unsigned long long* host, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_gstat), 16 * 8);
@@ -391,6 +400,8 @@ extern "C" int fdh_debug_read(uint32_t* host, uint32_t nwords, int reset) {
 // synchronises, so it must stay off the launch path)
 static fdh::CanonTables* g_canon_dev[64] = {};
 static uint32_t* g_span_pool[64] = {};  // per device: scratch of the span decoder (never freed)
+static int g_cu_count[64] = {};         // per device: compute units (0 = not asked yet)
+static std::mutex g_dev_mutex;          // guards the three per-device caches above
 
 extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status) {
     hipLaunchKernelGGL(fdh::canon_build_kernel, dim3(1), dim3(fdh::kWave), 0, stream);
@@ -404,7 +415,10 @@ extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status)
     e = hipMemcpy(host_status, &dev->status, sizeof(uint32_t), hipMemcpyDeviceToHost);
     int ordinal = 0;
     if (e == hipSuccess) e = hipGetDevice(&ordinal);
-    if (e == hipSuccess && ordinal >= 0 && ordinal < 64) g_canon_dev[ordinal] = dev;
+    if (e == hipSuccess && ordinal >= 0 && ordinal < 64) {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        g_canon_dev[ordinal] = dev;
+    }
     return (int)e;
 }
 
@@ -416,6 +430,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
     if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
         int ordinal = 0;
         if (hipGetDevice(&ordinal) == hipSuccess && ordinal >= 0 && ordinal < 64) {
+            std::lock_guard<std::mutex> lock(g_dev_mutex);
             if (!g_span_pool[ordinal]) {
                 const size_t bytes = ((size_t)fdh::kSpanSlots + (size_t)fdh::kSpanSlots * 2 * fdh::kSpanMaxMatches) * sizeof(uint32_t);
                 uint32_t* p = nullptr;
@@ -452,17 +467,21 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
             if (e != hipSuccess) return (int)e;
         }
-        fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->hdr,
+        fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->len4, canon->hdr,
                         fdh::kCanonBits, fdh::kPending, list};
         unsigned sblocks = (unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves);
         if (list) {  // persistent wavefronts: two workgroups (80 KiB of LDS each) per CU
-            static int cus[64] = {};
-            if (cus[ordinal & 63] == 0) {
-                int v = 0;
-                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ordinal) != hipSuccess || v <= 0) v = 256;
-                cus[ordinal & 63] = v;
+            int cus;
+            {
+                std::lock_guard<std::mutex> lock(g_dev_mutex);
+                if (g_cu_count[ordinal & 63] == 0) {
+                    int v = 0;
+                    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ordinal) != hipSuccess || v <= 0) v = 256;
+                    g_cu_count[ordinal & 63] = v;
+                }
+                cus = g_cu_count[ordinal & 63];
             }
-            sblocks = std::min(sblocks, (unsigned)(2 * cus[ordinal & 63]));
+            sblocks = std::min(sblocks, (unsigned)(2 * cus));
         }
         hipLaunchKernelGGL(fdh::inflate_segments_kernel, dim3(sblocks), dim3(fdh::kSegWaves * fdh::kWave), 0, stream, sa);
         e = hipGetLastError();

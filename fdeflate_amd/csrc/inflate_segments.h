@@ -4,8 +4,8 @@
 // src/compress/ultrafast.rs:82-88) is one final dynamic block with a known table.  Its block
 // data is cut into up to 64 equal bit ranges ("segments", >= kSegMinBits each; short streams use
 // fewer lanes), one per lane, and every lane runs the reference's inner loop
-// (src/decompress.rs:645-830: table look-up, 1-2 literals per step, dist-1 run) sequentially over
-// its own segment:
+// (src/decompress.rs:645-830: table look-up, literals, dist-1 run) sequentially over its own
+// segment:
 //
 //   pass 1  every lane decodes from the FIRST BIT of its segment -- a guess, the real symbol
 //           boundary lies up to 17 bits further: the first kSegWindow bits are only walked
@@ -25,10 +25,13 @@
 //           are combined with the block-combine identity.
 //
 // Input is read per lane through a 64-B LDS ring that is topped up at wavefront-uniform "events"
-// (one per kSegSteps steps, two adjacent 16-B loads at a time, committed an event later), so the
-// hot loops never wait on memory.  The hot loops themselves are hand-scheduled groups of
-// literal-only steps (seg_count_group / seg_write_group); any other entry is handled by a
-// select-only C++ step.
+// (one per two groups of steps, two adjacent 16-B loads at a time, committed an event later), so
+// the hot loops never wait on memory.  The hot loops themselves are hand-scheduled groups of
+// kSegSteps table look-ups (seg_count_group / seg_write_group) that run, under the execution
+// mask of the lanes that are at least a group away from their end, WITHOUT any per-step branch or
+// mask change: a table entry retires up to three literals; a run / end-of-block / impossible
+// entry is encoded as "0 bits, 0 bytes", so a lane that meets one simply marks time until the
+// pair of steps ends, and the select-only C++ step that follows every group decodes that token.
 // Anything unusual -- not canonical, a bad / truncated token, a full slot, a checksum
 // mismatch -- leaves the stream PENDING for the exact wave-per-stream kernels.
 #pragma once
@@ -38,6 +41,7 @@ namespace fdh {
 
 #ifdef FDH_DEBUG_TILES
 __device__ uint32_t g_segdbg[64 * 16];
+__device__ uint32_t g_segdbg2[16 * 16];
 #define SEGDBG(slot, val) do { if (sid < 64 && lane == 0) g_segdbg[sid * 16 + (slot)] = (val); } while (0)
 #define SEGDBG_ADD(slot, val) do { if (sid < 64 && lane == 0) g_segdbg[sid * 16 + (slot)] += (val); } while (0)
 __device__ uint32_t g_segtime[4096 * 8];
@@ -54,35 +58,57 @@ constexpr int kSegOutWords = 16;  // per-lane output ring, dwords
 constexpr int kSegChunk = 4;       // dwords per global load of a lane (16 B)
 constexpr int kSegWindow = 256;     // bits of a segment used for self-synchronisation (the default)
 constexpr int kSegWindowShort = 192;  // ... for streams of short codes
-constexpr int kSegSteps = kSegInWords / 2;  // table look-ups between two global-memory events
-constexpr uint32_t kSegNeed = (kSegSteps * 18 + 31) / 32;  // dwords a group of steps can consume (18 bits/token)
+constexpr int kSegSteps = kSegInWords / 2;  // table look-ups of a fast group / of a stretch of the window walks
+constexpr uint32_t kSegPairs = kSegSteps / 2;               // a fast group = kSegPairs pairs of look-ups
+constexpr uint32_t kSegGroupBits = kSegSteps * kLitBits;    // most stream bits a fast group consumes (literal steps only)
+constexpr uint32_t kSegTokenBits = 18;                      // longest token: 12-bit code + 5 extra bits + 1 distance bit
+constexpr uint32_t kSegNeed = (kSegSteps * kSegTokenBits + 31) / 32;  // dwords a stretch of general steps can consume
+// dwords one half of the hot loops can consume (a fast group + one general step), + 1 for the
+// word the groups prefetch
+constexpr uint32_t kSegHalfNeed = (kSegGroupBits + kSegTokenBits + 31) / 32 + 1;
 constexpr uint32_t kSegMinBits = 768;   // aim: no segment shorter than this (fewer lanes are used instead)
 constexpr uint32_t kSegBulkFill = 64;             // runs at least this long are stored line by line
 constexpr uint32_t kNoByte = 0x100;  // "no literal seen yet"
+// What an event can always guarantee before the two halves that follow it: with fewer dwords than
+// this in the ring a pair of chunks fits, so waiting for the pair in flight gets the lane there.
+constexpr uint32_t kSegEventNeed = kSegInWords - 2 * kSegChunk;
+static_assert(kSegHalfNeed <= kSegEventNeed, "one half must be able to run right after an event");
 
-// Table entry of this kernel (converted from the device layout of inflate_tables.h while staging).
-// The fields the hot loops need are whole bytes, so they are used straight from the entry:
-//   byte 0   bits consumed by the whole token [4:0] (a run: code + extra bits + the 1-bit distance
-//            code) | SE_RUN | SE_EOB | SE_BAD (cannot occur / invalid)
-//   byte 1   8 x literal bytes of the token (0, 8, 16)
-//   byte 2-3 literals: first byte, second byte;  runs: length base [24:16], extra-bit count [27:25]
-// The common case -- every running lane looks at a literal entry -- has byte 0 = bits consumed.
-enum : uint32_t { SE_RUN = 0x20, SE_EOB = 0x40, SE_BAD = 0x80, SE_SPECIAL = 0xE0 };
-__device__ __forceinline__ uint32_t seg_entry_from(uint32_t e) {
-    const uint32_t nb = e & 15, kind = (e >> 4) & 15;
-    if (kind == K_LIT1) return nb | (8u << 8) | (((e >> 8) & 0xFF) << 16);
-    if (kind == K_LIT2) return nb | (16u << 8) | (((e >> 8) & 0xFFFF) << 16);
-    if (kind == K_LEN) {
-        const uint32_t ex = (e >> 8) & 31, base = e >> 16;
-        return (nb + ex + 1) | SE_RUN | (base << 16) | (ex << 25);
+// Table entry of this kernel (built from the device layout of inflate_tables.h while staging):
+//   byte 0    [3:0] stream bits of the whole step, [5:4] literals of the step (1..3), [7:6] kind
+//   byte 1-3  kind SK_LIT: the literal bytes in output order (unused ones zero)
+// Kind SK_LIT: up to three literals whose codes fit the 12 index bits together.  A step whose
+// FIRST symbol is a run length / end-of-block / impossible code has kind != 0 and bits [5:0] = 0
+// ("no bits, no literals"): the branch-free groups drop a lane that meets one (v_cmpx) before
+// anything of the step is applied, and the general step decodes the token from the entry's upper
+// bytes: [11:8] code bits, and for a run [14:12] extra-bit count, [24:16] length base.
+enum : uint32_t { SK_LIT = 0x00, SK_RUN = 0x40, SK_EOB = 0x80, SK_BAD = 0xC0, SK_KIND = 0xC0 };
+__device__ __forceinline__ uint32_t seg_entry_build(const uint32_t* canon, uint32_t i) {
+    uint32_t used = 0, n = 0, lits = 0;
+    for (int k = 0; k < 3; k++) {
+        // the next symbol at the zero-extended rest of the index: right whenever its code ends
+        // inside the index bits (prefix code), which is what `used + len <= kLitBits` checks
+        const uint32_t e = canon[i >> used];
+        const uint32_t kind = (e >> 4) & 15;
+        if (kind != K_LIT1 && kind != K_LIT2) break;
+        const uint32_t len = (e >> 24) & 15;  // bits of the first symbol (both kinds, inflate_tables.h)
+        if (used + len > (uint32_t)kLitBits) break;
+        lits |= ((e >> 8) & 0xFF) << (8 * k);
+        used += len;
+        n++;
     }
-    if (kind == K_EOB) return nb | SE_EOB;
-    return SE_BAD;
+    if (n) return used | (n << 4) | (lits << 8);
+    const uint32_t c = canon[i];
+    const uint32_t nb = c & 15, kind = (c >> 4) & 15;
+    if (kind == K_LEN) return SK_RUN | (nb << 8) | (((c >> 8) & 7) << 12) | ((c >> 16) << 16);  // extra bits <= 5, base <= 258
+    if (kind == K_EOB) return SK_EOB | (nb << 8);
+    return SK_BAD;
 }
-__device__ __forceinline__ uint32_t seg_used(uint32_t e) { return e & 31; }
-__device__ __forceinline__ uint32_t seg_n8(uint32_t e) { return (e >> 8) & 0xFF; }
-// last literal byte of a literal entry (one literal: byte 2, two: byte 3)
-__device__ __forceinline__ uint32_t seg_lastlit(uint32_t e) { return (e >> (8 + seg_n8(e))) & 0xFF; }
+__device__ __forceinline__ uint32_t seg_used(uint32_t e) { return e & 15; }
+__device__ __forceinline__ uint32_t seg_n8(uint32_t e) { return (e & 0x30) >> 1; }  // 8 x literals
+// last literal byte of a literal entry (n literals: byte n)
+__device__ __forceinline__ uint32_t seg_lastlit(uint32_t e) { return (e >> seg_n8(e)) & 0xFF; }
+__device__ __forceinline__ bool seg_is_lit(uint32_t e) { return (e & SK_KIND) == 0 && (e & 0x30) != 0; }
 
 // Rings are [wavefront][word][lane]: any per-lane word index is bank-conflict free, and with
 // 16 x 64 dwords per ring the slot of (wavefront, lane) and the word index occupy disjoint bits of
@@ -108,6 +134,7 @@ struct SegArgs {
     uint64_t n;
     uint32_t flags;
     const uint32_t* canon_lit;  // kLitSize entries (device layout, inflate_tables.h)
+    const uint32_t* canon_len4; // 32 dwords: the code lengths of the literals 0..255, 4 bits each
     const uint32_t* canon_hdr;  // 14 dwords of prefix (last one masked)
     uint32_t canon_bits;
     uint32_t pending;
@@ -261,101 +288,65 @@ struct SegReader {
             has_a = has_b = true;
         }
     }
-    // One event per kSegSteps steps keeps up with a chunk per group; a group can consume up to
-    // kSegSteps * 18 bits = kSegNeed dwords, so denser stretches get extra (waiting) events.
+    // One event per stretch keeps up with the average consumption; `need` dwords must be in the
+    // ring before the stretch starts, so denser stretches get extra (waiting) events.
     __device__ __forceinline__ void events(bool running, uint32_t need = kSegNeed) {
         event(running);
         for (int x = 0; x < 2 && __any(running && level() < need); x++) event(running);
     }
 };
 
-// A run token, resolved: its length and whether its distance code is not the declared one.
-struct SegRun {
-    uint32_t length;
-    bool bad_dist;
+// One table step of any kind, decoded (the general, select-only form of a step).
+struct SegTok {
+    uint32_t e;       // the table entry (literal steps; a one-literal entry in the single-symbol zone)
+    uint32_t used;    // stream bits of the step
+    uint32_t n8;      // 8 x literal bytes (0 for a run / end-of-block / impossible token)
+    uint32_t run;     // run length (0: not a run)
+    bool eob, bad;
 };
-__device__ __forceinline__ SegRun seg_run(uint32_t e, uint32_t win) {
-    const uint32_t used = seg_used(e);
-    const uint32_t ex = (e >> 25) & 7;
-    const uint32_t code_bits = used - ex - 1;
-    SegRun r;
-    r.length = ((e >> 16) & 0x1FF) + ((win >> (code_bits & 31)) & ((1u << ex) - 1));
-    // the prefix declares one distance code: '0' = distance 1; it is the token's last bit
-    r.bad_dist = ((win >> ((used - 1) & 31)) & 1) != 0;
-    return r;
+// `need`: this lane wants the token.  `single`: take the first literal of the step alone (the
+// symbol-by-symbol zone at a window's end).  The length of the first literal alone is looked up in
+// `len4`, a 256 x 4-bit table kept in ONE VGPR (lane k < 32 holds the lengths of the literals
+// 8k .. 8k+7) and read with ds_bpermute -- no LDS memory, no global memory.  Call with all lanes of
+// the wavefront active (ds_bpermute reads zero from an inactive lane).
+__device__ __forceinline__ SegTok seg_token(const uint32_t* lit, uint32_t len4, uint32_t win, bool need, bool single) {
+    const uint32_t idx = win & (kLitSize - 1);
+    SegTok t;
+    t.e = lit[idx];
+    t.used = seg_used(t.e);
+    t.n8 = seg_n8(t.e);
+    const uint32_t kind = t.e & SK_KIND;
+    const uint32_t nb = (t.e >> 8) & 15, ex = (t.e >> 12) & 7, base = (t.e >> 16) & 0x1FF;
+    const bool is_run = kind == SK_RUN;
+    t.run = is_run ? base + ((win >> nb) & ((1u << ex) - 1)) : 0u;
+    t.used = is_run ? nb + ex + 1 : (kind == SK_EOB ? nb : t.used);
+    t.eob = kind == SK_EOB;
+    // the prefix declares one distance code: '0' = distance 1; it is the run token's last bit
+    t.bad = kind == SK_BAD || (is_run && ((win >> (nb + ex)) & 1) != 0);
+    const bool first_only = single && t.n8 > 8;
+    if (__any(need && first_only)) {
+        const uint32_t b1 = (t.e >> 8) & 0xFF;
+        const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b1 >> 3) << 2), (int)len4);
+        const uint32_t len1 = (w >> ((b1 & 7) * 4)) & 15;
+        t.used = first_only ? len1 : t.used;
+        t.n8 = first_only ? 8u : t.n8;
+        t.e = first_only ? ((t.e & 0xFF00u) | 0x10u | len1) : t.e;
+    }
+    return t;
 }
 
 // State of one lane's counting scan.
 struct SegScan {
     uint32_t pos;      // segment-relative bit position of the next token
     uint32_t count8;   // 8 x output bytes counted so far
-    uint32_t last_e;   // entry of the last literal token counted (0 if none)
+    uint32_t last_e;   // entry of the last literal step counted (0 if none)
     uint32_t stop;     // 0 none, 1 end-of-block (pos = its start, eob_bits its length), 2 bad token
     uint32_t eob_bits;
 };
 
-// Walks a chain through the synchronisation window: from s.pos until pos >= window (or a stop).
-// GUESS: the chain is only a way to find a synchronisation point -- nothing is counted, and an
-// impossible token (or a stray end-of-block) just means "not synchronised yet": slide on by one
-// bit.  The landing check is what guarantees correctness.  Otherwise (the real chain) every byte
-// is counted.  Close to the window's end a literal pair is taken one literal at a time: the
-// guessed and the real chain may pair literals differently, but they then still cross the window
-// on the same symbol boundary (the length of the first literal alone comes from the canonical
-// table in global memory: this happens two or three times per scan).
-template <bool GUESS>
-__device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, const uint32_t* canon_lit, SegReader& rd,
-                                                    uint32_t limit, bool active, uint32_t window, SegScan& s) {
-    bool running = active && s.pos < window;
-    uint32_t iter = 0;
-    while (__any(running)) {
-        rd.events(running);
-#pragma unroll 1
-        for (int k = 0; k < kSegSteps; k++) {
-            iter++;
-            const uint32_t win = rd.window();
-            const uint32_t e = lit[win & (kLitSize - 1)];
-            const uint32_t nw = rd.peek();
-            uint32_t used = seg_used(e), n8 = seg_n8(e);
-            const bool is_run = (e & SE_RUN) != 0;
-            bool is_eob = (e & SE_EOB) != 0;
-            bool bad = (e & SE_BAD) != 0;
-            uint32_t run = 0;
-            if (__any(running && is_run)) {
-                const SegRun r = seg_run(e, win);
-                run = is_run ? r.length : 0u;
-                bad = bad || (is_run && r.bad_dist);
-            }
-            uint32_t e_lit = e;
-            const bool single = n8 == 16 && s.pos + 24 >= window;
-            if (__any(running && single)) {
-                if (running && single) {
-                    used = canon_lit[win & (kLitSize - 1)] >> 24;  // K_LIT2: bits of the first symbol (inflate_tables.h)
-                    n8 = 8;
-                    e_lit = (e & 0x00FF0000u) | (8u << 8) | used;  // the first literal alone
-                }
-            }
-            if (GUESS) {
-                const bool slide = (bad || is_eob) && s.pos + 1 <= limit;
-                used = slide ? 1u : used;
-                bad = slide ? false : bad;
-                is_eob = slide ? false : is_eob;
-            }
-            const bool fault = bad || s.pos + used > limit;
-            const bool step = running && !fault && !is_eob;
-            const bool halt = running && !step;
-            s.stop = halt ? (fault ? 2u : 1u) : s.stop;
-            s.eob_bits = halt ? used : s.eob_bits;
-            if (!GUESS) {
-                s.count8 += step ? n8 + 8 * run : 0u;
-                s.last_e = (step && n8 != 0) ? e_lit : s.last_e;
-            }
-            const uint32_t adv = step ? used : 0u;
-            s.pos += adv;
-            rd.advance(adv, nw);
-            running = step && s.pos < window;
-        }
-    }
-    return iter;
+// The value of lane ^ 1 (DPP quad_perm [1,0,3,2]: a VALU move, no LDS traffic).  All lanes active.
+__device__ __forceinline__ uint32_t swap1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
 }
 
 // Byte offset of an LDS object inside the workgroup's LDS allocation.
@@ -363,151 +354,248 @@ __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-// Up to `left` literal-only steps of the counting loop, hand-scheduled.  The choice of
-// instructions follows their measured issue cost on gfx950 (two cycles per wavefront for plain
-// VOP2, four for VOP3 / compares / scalar instructions): the table entry's fields are whole
-// bytes, the entry itself is summed (byte 1 of the sum = 8 x bytes), the ring address is kept as
-// an LDS byte address, and the word hand-over at a dword boundary runs under the execution mask.
-// Stops in front of a step in which some running lane looks at a special entry and returns the
-// number of steps still to do (that step included); nothing of that step has been applied.
-// Requires the literal table at LDS offset 0.
-__device__ __forceinline__ uint32_t seg_count_group(uint32_t left, uint32_t lim, uint32_t ring_base, SegReader& rd,
-                                                    uint32_t& pos, uint32_t& gsum, uint32_t& last_e) {
+// kSegPairs pairs of look-ups of the counting loop, hand-scheduled, for the lanes the caller has
+// enabled (every one of them is >= kSegGroupBits in front of its end, so nothing is checked per
+// step).  The 64-bit window {lo, hi} lives in v[120:121]: a pair of steps consumes at most 24 bits,
+// so the window is shifted by 64-bit shifts twice and topped up ONCE per pair (selects, no
+// execution-mask change; the word after it is prefetched a pair ahead).  Per step: bits += e & 15,
+// cnt16 += e & 0x30 (16 x literals).  A step on a run / end-of-block / impossible entry adds
+// nothing; a lane that met one leaves the group at the end of that pair (v_cmpx clears its bit of
+// the execution mask, which is restored at the end) -- there is no branch but the loop's own.
+// eA / eB return the entries of the lane's last pair, `last` the second entry of the pair before
+// it (seg_last_after_group picks the lane's last literal entry from the three).  Requires the
+// literal table at LDS offset 0.  The choice of instructions follows their measured issue cost on
+// gfx950 (tools/ubench: ~2 cycles per wavefront for plain VOP2, ~4 for VOP3 and compares).
+#ifndef FDH_SEG_R0   // the four fixed VGPRs of the groups (an aligned pair for the window, one for the shifted window)
+#define FDH_SEG_R0 "120"
+#define FDH_SEG_R1 "121"
+#define FDH_SEG_R2 "122"
+#define FDH_SEG_R3 "123"
+#endif
+#define FDH_SEG_WLO "v" FDH_SEG_R0
+#define FDH_SEG_WHI "v" FDH_SEG_R1
+#define FDH_SEG_WIN "v[" FDH_SEG_R0 ":" FDH_SEG_R1 "]"
+#define FDH_SEG_SHF "v[" FDH_SEG_R2 ":" FDH_SEG_R3 "]"
+#define FDH_SEG_SH0 "v" FDH_SEG_R2
+#define FDH_SEG_CLOBBER "v" FDH_SEG_R0, "v" FDH_SEG_R1, "v" FDH_SEG_R2, "v" FDH_SEG_R3
+// Tops up the window after a pair of steps: b > 31 -> {lo, hi} = {hi, next word}, one more word is
+// read from the ring.  (gfx950 needs two instructions between a VALU write of VCC and a VALU read.)
+#define FDH_SEG_TOPUP_WINDOW                                                                              \
+    "  v_cmp_lt_u32 vcc, 31, %[b]\n"                                                                      \
+    "  v_and_b32 %[b], 31, %[b]\n"                                                                        \
+    "  v_mov_b32 %[last], %[eB]\n"                                                                        \
+    "  v_cndmask_b32 " FDH_SEG_WLO ", " FDH_SEG_WLO ", " FDH_SEG_WHI ", vcc\n"                            \
+    "  v_cndmask_b32 " FDH_SEG_WHI ", " FDH_SEG_WHI ", %[nw], vcc\n"                                      \
+    "  v_addc_co_u32 %[ird], vcc, 0, %[ird], vcc\n"                                                       \
+    "  v_lshlrev_b32 %[t], 8, %[ird]\n"                                                                   \
+    "  v_and_or_b32 %[ra], %[t], %[mf00], %[rb]\n"
+#define FDH_SEG_LOOP_END                                                                                  \
+    FDH_SEG_TOPUP_WINDOW                                                                                  \
+    "  ds_read_b32 %[nw], %[ra]\n"                                                                        \
+    "  s_sub_u32 %[pairs], %[pairs], 1\n"                                                                 \
+    "  s_cmp_lg_u32 %[pairs], 0\n"                                                                        \
+    "  s_cbranch_scc1 Lpair_%=\n"                                                                         \
+    "  s_mov_b64 exec, %[sv]\n" /* the lanes that left on the way are back: bring THEIR window in order */ \
+    "  s_waitcnt lgkmcnt(0)\n"                                                                            \
+    "  v_cmp_lt_u32 vcc, 31, %[b]\n"                                                                      \
+    "  v_and_b32 %[b], 31, %[b]\n"                                                                        \
+    "  s_nop 0\n"                                                                                         \
+    "  v_cndmask_b32 %[lo], " FDH_SEG_WLO ", " FDH_SEG_WHI ", vcc\n"                                      \
+    "  v_cndmask_b32 %[hi], " FDH_SEG_WHI ", %[nw], vcc\n"                                                \
+    "  v_addc_co_u32 %[ird], vcc, 0, %[ird], vcc\n"
+
+// `pairs` pairs of look-ups of the counting loop, hand-scheduled, for the lanes the caller has
+// enabled (every one of them is >= 24 * pairs bits in front of its end, so nothing is checked per
+// step).  The 64-bit window {lo, hi} lives in an aligned register pair: a pair of steps consumes at
+// most 24 bits, so the window is shifted by 64-bit shifts twice and topped up ONCE per pair
+// (selects, no execution-mask change; the word after it is prefetched a pair ahead).  Per step:
+// bits += e & 15, cnt16 += e & 0x30 (16 x literals).  A lane that meets a run / end-of-block /
+// impossible entry (no literals) leaves the group on the spot -- v_cmpx clears its bit of the
+// execution mask, nothing of that step is applied, the mask is restored at the end -- so there is
+// no branch but the loop's own.  eA / eB return the entries of the lane's last pair, `last` the
+// second entry of the pair before it (seg_last_after_group picks the lane's last literal entry from
+// the three).  Requires the literal table at LDS offset 0.  The choice of instructions follows
+// their measured issue cost on gfx950 (tools/ubench: ~2 cycles per wavefront for plain VOP2, ~4 for
+// VOP3 and compares); what bounds the loop is the dependent chain window -> index -> LDS -> bits
+// (~160 cycles a step, tools/ubench/seg_group.hip), i.e. the number of wavefronts per SIMD.
+#define FDH_SEG_COUNT_STEP(E)                                       \
+    "  v_lshrrev_b64 " FDH_SEG_SHF ", %[b], " FDH_SEG_WIN "\n"      \
+    "  v_and_b32 %[t], 0x3ffc, " FDH_SEG_SH0 "\n"                   \
+    "  ds_read_b32 %[" E "], %[t]\n"                                \
+    "  s_waitcnt lgkmcnt(0)\n"                                      \
+    "  v_and_b32 %[tn], 0x30, %[" E "]\n"                           \
+    "  v_cmpx_ne_u32 vcc, 0, %[tn]\n"                               \
+    "  v_and_b32 %[t], 15, %[" E "]\n"                              \
+    "  v_add_u32 %[b], %[b], %[t]\n"                                \
+    "  v_add_u32 %[cnt], %[cnt], %[tn]\n"
+__device__ __forceinline__ void seg_count_group(uint32_t pairs, uint32_t ring_base, SegReader& rd, uint32_t& cnt16,
+                                                uint32_t& last, uint32_t& eA, uint32_t& eB) {
     static_assert(kSegInWords == 16, "ring word mask 0xf00 below");
     uint32_t ra = ring_base | ((rd.in_rd << 8) & 0xf00u);
-    uint32_t w2, e, nw, t;
+    uint32_t nw, t, tn;
     uint64_t sv;
+    uint32_t mf00 = 0xf00u;
+    eA = eB = last;
     asm volatile(
-        "  s_waitcnt lgkmcnt(0)\n"  // nothing of the compiler's may be in flight: the counted waits below assume it
-        "Lstep_%=:\n"
-        "  v_alignbit_b32 %[w2], %[hi], %[lo], %[b]\n"
-        "  v_and_b32 %[t], 0x3ffc, %[w2]\n"
-        "  ds_read_b32 %[e], %[t]\n"
+        "  s_waitcnt lgkmcnt(0)\n"  // nothing of the compiler's may be in flight: the waits below assume it
+        "  s_mov_b64 %[sv], exec\n"
+        "  v_mov_b32 " FDH_SEG_WLO ", %[lo]\n"
+        "  v_mov_b32 " FDH_SEG_WHI ", %[hi]\n"
         "  ds_read_b32 %[nw], %[ra]\n"
-        "  v_cmp_lt_u32 vcc, %[pos], %[lim]\n"
-        "  s_and_saveexec_b64 %[sv], vcc\n"
-        "  s_waitcnt lgkmcnt(1)\n"
-        "  v_and_b32 %[t], 0xe0, %[e]\n"
-        "  v_cmp_ne_u32 vcc, 0, %[t]\n"
-        "  s_cbranch_vccnz Lspecial_%=\n"
-        "  v_and_b32 %[t], 0xff, %[e]\n"
-        "  v_add_u32 %[gsum], %[gsum], %[e]\n"
-        "  v_mov_b32 %[last], %[e]\n"
-        "  v_add_u32 %[pos], %[pos], %[t]\n"
-        "  v_add_u32 %[b], %[b], %[t]\n"
-        "  v_cmp_lt_u32 vcc, 31, %[b]\n"
-        "  v_and_b32 %[b], 31, %[b]\n"
-        "  s_and_b64 exec, exec, vcc\n"
-        "  s_waitcnt lgkmcnt(0)\n"
-        "  v_mov_b32 %[lo], %[hi]\n"
-        "  v_mov_b32 %[hi], %[nw]\n"
-        "  v_add_u32 %[t], 0x100, %[ra]\n"
-        "  v_and_b32 %[t], 0xf00, %[t]\n"
-        "  v_or_b32 %[ra], %[rb], %[t]\n"
-        "  v_add_u32 %[ird], 1, %[ird]\n"
-        "  s_mov_b64 exec, %[sv]\n"
-        "  s_sub_u32 %[left], %[left], 1\n"
-        "  s_cmp_lg_u32 %[left], 0\n"
-        "  s_cbranch_scc1 Lstep_%=\n"
-        "  s_branch Ldone_%=\n"
-        "Lspecial_%=:\n"
-        "  s_mov_b64 exec, %[sv]\n"
-        "Ldone_%=:\n"
-        "  s_waitcnt lgkmcnt(0)\n"
-        : [left] "+s"(left), [pos] "+v"(pos), [gsum] "+v"(gsum), [last] "+v"(last_e), [lo] "+v"(rd.lo),
-          [hi] "+v"(rd.hi), [b] "+v"(rd.boff), [ra] "+v"(ra), [ird] "+v"(rd.in_rd), [w2] "=&v"(w2), [e] "=&v"(e),
-          [nw] "=&v"(nw), [t] "=&v"(t), [sv] "=&s"(sv)
-        : [lim] "v"(lim), [rb] "v"(ring_base)
-        : "vcc", "scc", "memory");
-    return left;
+        "Lpair_%=:\n"
+        FDH_SEG_COUNT_STEP("eA")
+        FDH_SEG_COUNT_STEP("eB")
+        FDH_SEG_LOOP_END
+        : [pairs] "+s"(pairs), [cnt] "+v"(cnt16), [last] "+v"(last), [lo] "+v"(rd.lo), [hi] "+v"(rd.hi),
+          [b] "+v"(rd.boff), [ra] "+v"(ra), [ird] "+v"(rd.in_rd), [eA] "+v"(eA), [eB] "+v"(eB), [nw] "=&v"(nw),
+          [t] "=&v"(t), [tn] "=&v"(tn), [sv] "=&s"(sv)
+        : [rb] "v"(ring_base), [mf00] "s"(mf00)
+        : "vcc", "scc", "memory", FDH_SEG_CLOBBER);
 }
+#undef FDH_SEG_COUNT_STEP
 
-// Up to `left` literal-only steps of the writing loop (pass 2), hand-scheduled like
-// seg_count_group: decode one entry, append its 1-2 bytes to the 4-byte accumulator, move the
-// accumulator to the output ring when it is full (a partial one stays in its register).
-// Entered only while no lane is filling a run.  Returns the steps still to do when some running
-// lane meets a special entry (nothing of that step applied).
+// The same for the writing loop (pass 2): each step also appends its <= 3 literal bytes to the
+// 4-byte accumulator; the accumulator is written to its ring slot every step (the slot at vposw is
+// always free) and only counts -- vposw moves on -- once it is full.
 struct SegWriter {
     uint32_t acc, sh, vposw;
 };
-__device__ __forceinline__ uint32_t seg_write_group(uint32_t left, uint32_t end2, uint32_t ring_base, uint32_t out_base,
-                                                    SegReader& rd, SegWriter& wr, uint32_t& pos, uint32_t& last_e) {
+#define FDH_SEG_WRITE_STEP(E)                                                                           \
+    "  v_lshrrev_b64 " FDH_SEG_SHF ", %[b], " FDH_SEG_WIN "\n"                                          \
+    "  v_and_b32 %[t], 0x3ffc, " FDH_SEG_SH0 "\n"                                                       \
+    "  ds_read_b32 %[" E "], %[t]\n"                                                                    \
+    "  s_waitcnt lgkmcnt(0)\n"                                                                          \
+    "  v_and_b32 %[tn], 0x30, %[" E "]\n"                                                               \
+    "  v_cmpx_ne_u32 vcc, 0, %[tn]\n"                                                                   \
+    "  v_lshrrev_b32 %[v], 8, %[" E "]\n"        /* the literal bytes */                               \
+    "  v_lshlrev_b32 %[t], %[sh], %[v]\n"                                                               \
+    "  v_or_b32 %[acc], %[acc], %[t]\n"                                                                 \
+    "  v_sub_u32 %[t], 32, %[sh]\n"                                                                     \
+    "  v_lshrrev_b32 %[v], %[t], %[v]\n"         /* bytes that did not fit (used when full: sh > 0) */  \
+    "  v_lshrrev_b32 %[tn], 1, %[tn]\n"                                                                 \
+    "  v_add_u32 %[sh], %[sh], %[tn]\n"                                                                 \
+    "  ds_write_b32 %[wa], %[acc]\n"                                                                    \
+    "  v_cmp_lt_u32 vcc, 31, %[sh]\n"                                                                   \
+    "  v_and_b32 %[sh], 31, %[sh]\n"                                                                    \
+    "  v_and_b32 %[t], 15, %[" E "]\n"                                                                  \
+    "  v_add_u32 %[b], %[b], %[t]\n"                                                                    \
+    "  v_cndmask_b32 %[acc], %[acc], %[v], vcc\n"                                                       \
+    "  v_addc_co_u32 %[vposw], vcc, 0, %[vposw], vcc\n"                                                 \
+    "  v_lshlrev_b32 %[t], 8, %[vposw]\n"                                                               \
+    "  v_and_or_b32 %[wa], %[t], %[mf00], %[ob]\n"
+__device__ __forceinline__ void seg_write_group(uint32_t pairs, uint32_t ring_base, uint32_t out_base, SegReader& rd,
+                                                SegWriter& wr, uint32_t& last, uint32_t& eA, uint32_t& eB) {
     static_assert(kSegInWords == 16 && kSegOutWords == 16, "ring word mask 0xf00 below");
     uint32_t ra = ring_base | ((rd.in_rd << 8) & 0xf00u);
     uint32_t wa = out_base | ((wr.vposw << 8) & 0xf00u);
-    uint32_t w2, e, nw, t, v;
-    uint64_t sv, sr;
+    uint32_t nw, t, v, tn;
+    uint64_t sv;
+    uint32_t mf00 = 0xf00u;
+    eA = eB = last;
     asm volatile(
-        "  s_waitcnt lgkmcnt(0)\n"  // nothing of the compiler's may be in flight: the counted waits below assume it
-        "Lstep_%=:\n"
-        "  v_alignbit_b32 %[w2], %[hi], %[lo], %[b]\n"
-        "  v_and_b32 %[t], 0x3ffc, %[w2]\n"
-        "  ds_read_b32 %[e], %[t]\n"
+        "  s_waitcnt lgkmcnt(0)\n"
+        "  s_mov_b64 %[sv], exec\n"
+        "  v_mov_b32 " FDH_SEG_WLO ", %[lo]\n"
+        "  v_mov_b32 " FDH_SEG_WHI ", %[hi]\n"
         "  ds_read_b32 %[nw], %[ra]\n"
-        "  v_cmp_lt_u32 vcc, %[pos], %[end2]\n"
-        "  s_and_saveexec_b64 %[sv], vcc\n"
-        "  s_waitcnt lgkmcnt(1)\n"
-        "  v_and_b32 %[t], 0xe0, %[e]\n"
-        "  v_cmp_ne_u32 vcc, 0, %[t]\n"
-        "  s_cbranch_vccnz Lspecial_%=\n"
-        "  v_and_b32 %[t], 0xff, %[e]\n"
-        "  v_mov_b32 %[last], %[e]\n"
-        "  v_add_u32 %[pos], %[pos], %[t]\n"
-        "  v_add_u32 %[b], %[b], %[t]\n"
-        // append the literal bytes (entry bits 31:16) at byte sh / 8 of the accumulator
-        "  v_lshrrev_b32 %[v], 16, %[e]\n"
-        "  v_lshlrev_b32 %[t], %[sh], %[v]\n"
-        "  v_or_b32 %[acc], %[acc], %[t]\n"
-        "  v_sub_u32 %[t], 32, %[sh]\n"
-        "  v_lshrrev_b32 %[v], %[t], %[v]\n"  // bytes that did not fit (only used when the word fills up, sh > 0)
-        "  v_lshrrev_b32 %[t], 8, %[e]\n"
-        "  v_and_b32 %[t], 0xff, %[t]\n"
-        "  v_add_u32 %[sh], %[sh], %[t]\n"
-        "  v_cmp_lt_u32 vcc, 31, %[sh]\n"
-        "  v_and_b32 %[sh], 31, %[sh]\n"
-        "  s_mov_b64 %[sr], exec\n"
-        "  s_and_b64 exec, exec, vcc\n"  // lanes whose accumulator is full: it goes to the ring
-        "  ds_write_b32 %[wa], %[acc]\n"
-        "  v_mov_b32 %[acc], %[v]\n"
-        "  v_add_u32 %[t], 0x100, %[wa]\n"
-        "  v_and_b32 %[t], 0xf00, %[t]\n"
-        "  v_or_b32 %[wa], %[ob], %[t]\n"
-        "  v_add_u32 %[vposw], 1, %[vposw]\n"
-        "  s_mov_b64 exec, %[sr]\n"
-        "  v_cmp_lt_u32 vcc, 31, %[b]\n"
-        "  v_and_b32 %[b], 31, %[b]\n"
-        "  s_and_b64 exec, exec, vcc\n"  // lanes that crossed a dword of input
-        "  s_waitcnt lgkmcnt(0)\n"
-        "  v_mov_b32 %[lo], %[hi]\n"
-        "  v_mov_b32 %[hi], %[nw]\n"
-        "  v_add_u32 %[t], 0x100, %[ra]\n"
-        "  v_and_b32 %[t], 0xf00, %[t]\n"
-        "  v_or_b32 %[ra], %[rb], %[t]\n"
-        "  v_add_u32 %[ird], 1, %[ird]\n"
-        "  s_mov_b64 exec, %[sv]\n"
-        "  s_sub_u32 %[left], %[left], 1\n"
-        "  s_cmp_lg_u32 %[left], 0\n"
-        "  s_cbranch_scc1 Lstep_%=\n"
-        "  s_branch Ldone_%=\n"
-        "Lspecial_%=:\n"
-        "  s_mov_b64 exec, %[sv]\n"
-        "Ldone_%=:\n"
-        "  s_waitcnt lgkmcnt(0)\n"
-        : [left] "+s"(left), [pos] "+v"(pos), [last] "+v"(last_e), [lo] "+v"(rd.lo), [hi] "+v"(rd.hi),
-          [b] "+v"(rd.boff), [ra] "+v"(ra), [ird] "+v"(rd.in_rd), [acc] "+v"(wr.acc), [sh] "+v"(wr.sh),
-          [wa] "+v"(wa), [vposw] "+v"(wr.vposw), [w2] "=&v"(w2), [e] "=&v"(e), [nw] "=&v"(nw), [t] "=&v"(t),
-          [v] "=&v"(v), [sv] "=&s"(sv), [sr] "=&s"(sr)
-        : [end2] "v"(end2), [rb] "v"(ring_base), [ob] "v"(out_base)
-        : "vcc", "scc", "memory");
-    return left;
+        "Lpair_%=:\n"
+        FDH_SEG_WRITE_STEP("eA")
+        FDH_SEG_WRITE_STEP("eB")
+        FDH_SEG_LOOP_END
+        : [pairs] "+s"(pairs), [last] "+v"(last), [lo] "+v"(rd.lo), [hi] "+v"(rd.hi), [b] "+v"(rd.boff), [ra] "+v"(ra),
+          [ird] "+v"(rd.in_rd), [acc] "+v"(wr.acc), [sh] "+v"(wr.sh), [wa] "+v"(wa), [vposw] "+v"(wr.vposw),
+          [eA] "+v"(eA), [eB] "+v"(eB), [nw] "=&v"(nw), [t] "=&v"(t), [v] "=&v"(v), [tn] "=&v"(tn), [sv] "=&s"(sv)
+        : [rb] "v"(ring_base), [ob] "v"(out_base), [mf00] "s"(mf00)
+        : "vcc", "scc", "memory", FDH_SEG_CLOBBER);
+}
+#undef FDH_SEG_WRITE_STEP
+#undef FDH_SEG_LOOP_END
+#undef FDH_SEG_TOPUP_WINDOW
+
+// After a fast group: the last literal entry the lane has seen (for a run that follows).  A lane
+// leaves the group at the step in which it meets an entry without literals: at the first step of a
+// pair (eA is that entry; eB and `last` are the second entry of the pair before) or at the second
+// (eB is that entry, eA the literal entry in front of it).
+__device__ __forceinline__ uint32_t seg_last_after_group(uint32_t last, uint32_t eA, uint32_t eB) {
+    return (eA & SK_KIND) ? last : ((eB & SK_KIND) ? eA : eB);
+}
+
+// Walks a chain through the synchronisation window: from s.pos until pos >= window (or a stop).
+// GUESS: the chain is only a way to find a synchronisation point -- nothing is counted, and an
+// impossible token (or a stray end-of-block) just means "not synchronised yet": slide on by one
+// bit.  The landing check is what guarantees correctness.  Otherwise (the real chain) every byte
+// is counted.  In the last kLitBits bits of the window a step is taken one literal at a time: the
+// guessed and the real chain may group literals differently, but they then still cross the window
+// on the same symbol boundary (the length of the first literal alone comes from the canonical
+// table in global memory: this happens two or three times per scan).  In front of that zone the
+// lanes run the same fast groups as the counting loop (4 or 2 pairs of look-ups).
+template <bool GUESS>
+__device__ __forceinline__ uint32_t seg_window_scan(const uint32_t* lit, uint32_t len4, SegReader& rd,
+                                                    uint32_t limit, bool active, uint32_t window, SegScan& s) {
+    bool running = active && s.pos < window;
+    uint32_t iter = 0;
+    const uint32_t ring_base = lds_offset(rd.ring) + 4 * rd.lane_off;
+    const uint32_t zone = window - kLitBits;  // first bit of the symbol-by-symbol zone
+    while (__any(running)) {
+        rd.events(running, kSegEventNeed);
+        for (int half = 0; half < 2; half++) {
+            const uint32_t room = min(zone, limit);
+            const bool f4 = running && s.pos + kSegGroupBits <= room && rd.level() >= kSegHalfNeed;
+            const bool f2 = running && s.pos + kSegGroupBits / 2 <= room && rd.level() >= kSegHalfNeed;
+            const uint32_t pairs = __any(f4) ? kSegPairs : kSegPairs / 2;
+            const bool fast = pairs == kSegPairs ? f4 : f2;
+            bool general = running && !fast && rd.level() >= 2;
+            if (__any(fast)) {
+                if (fast) {
+                    uint32_t cnt16 = 0, eA, eB, last = s.last_e;
+                    const uint32_t b0 = rd.boff, r0 = rd.in_rd;
+                    seg_count_group(pairs, ring_base, rd, cnt16, last, eA, eB);
+                    s.pos += 32 * (rd.in_rd - r0) + rd.boff - b0;
+                    if (!GUESS) {
+                        s.count8 += cnt16 >> 1;
+                        s.last_e = seg_last_after_group(last, eA, eB);
+                    }
+                    general = ((eA | eB) & SK_KIND) != 0;
+                }
+                iter += 2 * pairs;
+            }
+            if (__any(general)) {
+                iter++;
+                const uint32_t win = rd.window();
+                const uint32_t nw = rd.peek();
+                SegTok t = seg_token(lit, len4, win, general, s.pos >= zone);
+                if (GUESS) {
+                    const bool slide = (t.bad || t.eob) && s.pos + 1 <= limit;
+                    t.used = slide ? 1u : t.used;
+                    t.n8 = slide ? 0u : t.n8;
+                    t.run = slide ? 0u : t.run;
+                    t.bad = slide ? false : t.bad;
+                    t.eob = slide ? false : t.eob;
+                }
+                const bool fault = t.bad || s.pos + t.used > limit;
+                const bool step = general && !fault && !t.eob;
+                const bool halt = general && !step;
+                s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+                s.eob_bits = halt ? t.used : s.eob_bits;
+                if (!GUESS) {
+                    s.count8 += step ? t.n8 + 8 * t.run : 0u;
+                    s.last_e = (step && t.n8 != 0) ? t.e : s.last_e;
+                }
+                const uint32_t adv = step ? t.used : 0u;
+                s.pos += adv;
+                rd.advance(adv, nw);
+                running = running && !halt;
+            }
+            running = running && s.pos < window;
+        }
+    }
+    return iter;
 }
 
 // The long loop of pass 1: from s.pos to `stop_at`, counting every byte.
-// Outer loop = one global-memory event, inner loop = kSegSteps look-ups that touch neither the
-// in-flight load registers nor global memory, so the compiler keeps waits and copies out of it.
-// A step is the literal fast path (a dozen byte-field operations under the execution mask) unless
-// some running lane looks at a run / end-of-block / impossible entry.  A lane runs while
-// pos < lim; halting sets lim = 0.
+// Outer loop = one global-memory event, then two halves of {fast group for the lanes that are at
+// least a group away from stop_at, one general step for the lanes that are not or that met a
+// run / end-of-block / impossible entry}.  A lane runs while pos < lim; halting sets lim = 0.
 __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReader& rd, uint32_t limit, bool active,
                                                    uint32_t stop_at, SegScan& s) {
     uint32_t lim = (active && s.stop == 0) ? stop_at : 0u;
@@ -515,44 +603,44 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
     const uint32_t ring_base = lds_offset(rd.ring) + 4 * rd.lane_off;
     if (s.pos < lim) rd.refill_now();
     while (__any(s.pos < lim)) {
-        // nothing is drained in this pass, so one memory event serves two groups of steps (a pair of
-        // chunks = 8 dwords per event covers the <= 2 * kSegNeed - 1 dwords they can consume)
-        rd.events(s.pos < lim, 2 * kSegNeed - 1);
-      for (int half = 0; half < 2; half++) {
-        uint32_t gsum = 0;  // sum of the literal entries of this group: byte 1 = 8 x bytes (<= 8 x 16)
-        uint32_t left = kSegSteps;
-        while (left) {
-            left = seg_count_group(left, lim, ring_base, rd, s.pos, gsum, s.last_e);
-            if (left == 0) break;
-            // general step (selects only): some running lane looks at a run / end-of-block / impossible entry
-            left--;
-            iter++;
-            const uint32_t win = rd.window();
-            const uint32_t e = lit[win & (kLitSize - 1)];
-            const uint32_t nw = rd.peek();
-            const bool running = s.pos < lim;
-            const uint32_t used = seg_used(e);
-            const bool is_run = (e & SE_RUN) != 0;
-            const SegRun r = seg_run(e, win);
-            const bool fault = (e & SE_BAD) != 0 || (is_run && r.bad_dist) || s.pos + used > limit;
-            const bool step = running && !fault && (e & SE_EOB) == 0;
-            const bool halt = running && !step;
-            s.stop = halt ? (fault ? 2u : 1u) : s.stop;
-            s.eob_bits = halt ? used : s.eob_bits;
-            lim = halt ? 0u : lim;
-            s.count8 += step ? (is_run ? 8 * r.length : seg_n8(e)) : 0u;
-            s.last_e = (step && seg_n8(e) != 0) ? e : s.last_e;
-            const uint32_t adv = step ? used : 0u;
-            s.pos += adv;
-            rd.advance(adv, nw);
+        rd.events(s.pos < lim, kSegEventNeed);
+        for (int half = 0; half < 2; half++) {
+            // a fast group must stay inside the lane's range and inside the stream, and needs its
+            // input in the ring (a lane that is short of input sits this half out: rare, dense data)
+            const bool fast = s.pos + kSegGroupBits <= min(lim, limit) && rd.level() >= kSegHalfNeed;
+            bool general = s.pos < lim && !fast && rd.level() >= 2;
+            if (__any(fast)) {
+                iter += (uint32_t)__popcll(__ballot(fast)) << 16;
+                if (fast) {
+                    uint32_t cnt16 = 0, eA, eB;
+                    const uint32_t b0 = rd.boff, r0 = rd.in_rd;
+                    seg_count_group(kSegPairs, ring_base, rd, cnt16, s.last_e, eA, eB);
+                    s.pos += 32 * (rd.in_rd - r0) + rd.boff - b0;
+                    s.count8 += cnt16 >> 1;
+                    s.last_e = seg_last_after_group(s.last_e, eA, eB);
+                    general = ((eA | eB) & SK_KIND) != 0;
+                }
+                iter += 1u << 8;
+            }
+            if (__any(general)) {
+                // general step (selects only): a token of any kind
+                iter++;
+                const uint32_t win = rd.window();
+                const uint32_t nw = rd.peek();
+                const SegTok t = seg_token(lit, 0u, win, general, false);
+                const bool fault = t.bad || s.pos + t.used > limit;
+                const bool step = general && !fault && !t.eob;
+                const bool halt = general && !step;
+                s.stop = halt ? (fault ? 2u : 1u) : s.stop;
+                s.eob_bits = halt ? t.used : s.eob_bits;
+                lim = halt ? 0u : lim;
+                s.count8 += step ? t.n8 + 8 * t.run : 0u;
+                s.last_e = (step && t.n8 != 0) ? t.e : s.last_e;
+                const uint32_t adv = step ? t.used : 0u;
+                s.pos += adv;
+                rd.advance(adv, nw);
+            }
         }
-        s.count8 += (gsum >> 8) & 0xFF;
-        iter += kSegSteps;
-      }
-        // the fast path checks neither of these per step; both are monotone within a group
-        const bool over = active && s.stop == 0 && (s.pos > limit || rd.starved());
-        s.stop = over ? 2u : s.stop;
-        lim = over ? 0u : lim;
     }
     return iter;
 }
@@ -563,17 +651,17 @@ struct SegPlan {
     uint32_t end2;    // chain end (>= segment length) or the end-of-block position; 0 = lane has nothing to do
     uint32_t obase;   // output offset of the lane's first byte
     uint32_t count;   // output bytes of the lane
-    uint32_t last_e;  // entry of the last literal token in front of the lane (0: none)
+    uint32_t last_e;  // entry of the last literal step in front of the lane (0: none)
     uint32_t total;   // uniform: output bytes of the stream
     uint32_t tb;      // uniform: stream byte position of the Adler-32 trailer
 };
-constexpr uint32_t kSegPlanWords = 5 * kWave + 4;  // per stream in global scratch: 5 lane arrays + {ok, total, tb, -}
 
 // Passes 1 + check + scan of one stream.  False: the stream was left PENDING (or is out of range).
 __device__ __forceinline__ bool segments_plan(const SegArgs& a, const uint32_t* lit, uint32_t* in_ring, const uint32_t lane_off,
                                               const uint64_t sid, SegPlan& plan) {
     const int lane = threadIdx.x & (kWave - 1);
     if (sid >= a.n) return false;
+    const uint32_t len4 = a.canon_len4[lane & 31];  // lengths of the literal codes, 4 bits each (seg_token)
 
     // ---- stream set-up (uniform) ----
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
@@ -597,7 +685,6 @@ __device__ __forceinline__ bool segments_plan(const SegArgs& a, const uint32_t* 
         }
         ours = !__any(mismatch);
     }
-    ours = ours && lds_offset(lit) == 0;  // the hand-scheduled loops address the table from LDS offset 0
     if (!ours) {
         if (lane == 0) seg_leave_pending(a, sid);
         return false;
@@ -636,7 +723,7 @@ __device__ __forceinline__ bool segments_plan(const SegArgs& a, const uint32_t* 
     SEGTIME(0);
     if (in_range) rd.start(in, seg_bit0);
     {
-        uint32_t itw = seg_window_scan<true>(lit, a.canon_lit, rd, limit, in_range, window, tail);
+        uint32_t itw = seg_window_scan<true>(lit, len4, rd, limit, in_range, window, tail);
         (void)itw;
         SEGDBG(6, itw);
         SEGDBG(1, 0);
@@ -677,7 +764,7 @@ __device__ __forceinline__ bool segments_plan(const SegArgs& a, const uint32_t* 
             rd.start(in, seg_bit0 + start);
         }
         {
-            uint32_t ith = seg_window_scan<false>(lit, a.canon_lit, rd, limit, need, window, head);
+            uint32_t ith = seg_window_scan<false>(lit, len4, rd, limit, need, window, head);
             (void)ith;
             SEGDBG_ADD(1, ith);
             SEGDBG_ADD(3, 1);
@@ -729,7 +816,7 @@ __device__ __forceinline__ bool segments_plan(const SegArgs& a, const uint32_t* 
     ok = ok && total64 <= cap;
     const uint32_t total = (uint32_t)total64;
     const uint32_t obase = (uint32_t)incl - count;
-    // last literal token of every lane's chain -> the byte a leading run of the right neighbour repeats
+    // last literal step of every lane's chain -> the byte a leading run of the right neighbour repeats
     uint32_t carry = live ? (tail.last_e != 0 ? tail.last_e : head.last_e) : 0u;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
@@ -796,8 +883,10 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     // start anywhere; the first and the last line of a lane are stored byte by byte)
     const uint32_t pad = (uint32_t)(reinterpret_cast<uintptr_t>(op) + obase) & 15;
     uint8_t* const line0 = op + obase - pad;    // 16-B aligned; may lie in front of the slot for lane 0
-    uint32_t vposw = pad >> 2;                  // virtual position in dwords: words already in the ring
-    uint32_t acc = 0, sh = 8 * (pad & 3);       // 4-byte accumulator holding sh / 8 bytes (the rest is zero)
+    SegWriter wr;
+    wr.vposw = pad >> 2;                        // virtual position in dwords: words already in the ring
+    wr.acc = 0;
+    wr.sh = 8 * (pad & 3);                      // 4-byte accumulator holding sh / 8 bytes (the rest is zero)
     uint32_t vstored = 0;                       // virtual bytes stored to global (multiple of 16)
     uint32_t ad_a = 0, ad_b = 0, blocks = 0;    // per-lane Adler partial over its own bytes
     uint32_t fill = 0;
@@ -810,17 +899,12 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
 
     // 16 virtual bytes at vs: to global memory (unless a neighbour lane has stored them, see drain) and
     // into the checksum
-    auto store_piece = [&](uint32_t vs, bool stored_already = false) __attribute__((always_inline)) {
-        const uint32_t w = vs >> 2;
-        uint4 q;
-        q.x = oring[seg_slot(lane_off, w + 0)];
-        q.y = oring[seg_slot(lane_off, w + 1)];
-        q.z = oring[seg_slot(lane_off, w + 2)];
-        q.w = oring[seg_slot(lane_off, w + 3)];
+    auto account_piece = [&](const uint4 q, uint32_t vs, bool stored_already) __attribute__((always_inline)) {
         if (stored_already) {
         } else if (vs >= pad && vs + 16 <= vend) {
             *reinterpret_cast<uint4*>(line0 + vs) = q;
-        } else {  // first / last line of this lane: only its own bytes
+        } else {  // first / last line of this lane: only its own bytes (unrolled: no indexed access to q)
+#pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
                 const uint32_t word = k < 4 ? q.x : (k < 8 ? q.y : (k < 12 ? q.z : q.w));
                 if (vs + k >= pad && vs + k < vend) line0[vs + k] = (uint8_t)(word >> (8 * (k & 3)));
@@ -840,9 +924,18 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
             blocks = 0;
         }
     };
+    auto ring_line = [&](uint32_t sl, uint32_t w) __attribute__((always_inline)) {
+        uint4 q;
+        q.x = oring[seg_slot(sl, w + 0)];
+        q.y = oring[seg_slot(sl, w + 1)];
+        q.z = oring[seg_slot(sl, w + 2)];
+        q.w = oring[seg_slot(sl, w + 3)];
+        return q;
+    };
+    auto store_piece = [&](uint32_t vs) __attribute__((always_inline)) { account_piece(ring_line(lane_off, vs >> 2), vs, false); };
     auto drain_all = [&]() __attribute__((always_inline)) {  // every complete 16-B line
-        while (__any(4 * vposw - vstored >= 16)) {
-            if (4 * vposw - vstored >= 16) {
+        while (__any(4 * wr.vposw - vstored >= 16)) {
+            if (4 * wr.vposw - vstored >= 16) {
                 store_piece(vstored);
                 vstored += 16;
             }
@@ -850,47 +943,43 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     };
     // Lines leave in 32-B aligned pairs (two adjacent 16-B stores back to back) so that whole
     // 32-B sectors reach the L2 together; a lane whose first line is the upper half of a sector
-    // sends that one alone.  < 32 B stay behind, + <= 32 B per group of steps: fits the 64-B ring.
+    // sends that one alone.  < 32 B stay behind, + <= 28 B per half (a group of 3-byte steps and a
+    // general step): fits the 64-B ring with the slot of the open accumulator.
     const bool odd_first = (reinterpret_cast<uintptr_t>(line0) & 16) != 0;
     auto drain = [&]() __attribute__((always_inline)) {
         for (;;) {
-            const uint32_t avail = 4 * vposw - vstored;
+            const uint32_t avail = 4 * wr.vposw - vstored;
             const bool single = odd_first && vstored == 0 && avail >= 16;
             const bool pair = !single && avail >= 32;
             if (!__any(single || pair)) break;
             // An interior pair is stored by two lanes in ONE instruction (lane l and l ^ 1 each write
             // 16 of the 32 bytes: first the pairs of the even lanes, then those of the odd lanes), so
-            // the memory pipeline sees 32-B requests instead of twice 16 B.
+            // the memory pipeline sees 32-B requests instead of twice 16 B.  Every lane reads its own
+            // two lines from the ring once (store + checksum); the neighbour's second line and
+            // pointer come over DPP.
             const bool coop = pair && vstored >= pad && vstored + 32 <= vend;
-            {
-                uint8_t* const my_ptr = line0 + vstored;
-                const uint32_t my_w = vstored >> 2;
-                const uint32_t p_lo = __shfl_xor((uint32_t)reinterpret_cast<uintptr_t>(my_ptr), 1, kWave);
-                const uint32_t p_hi = __shfl_xor((uint32_t)(reinterpret_cast<uintptr_t>(my_ptr) >> 32), 1, kWave);
-                const uint32_t p_w = __shfl_xor(my_w, 1, kWave);
-                const bool p_coop = __shfl_xor((int)coop, 1, kWave) != 0;
-                uint8_t* const p_ptr = reinterpret_cast<uint8_t*>(((uintptr_t)p_hi << 32) | p_lo);
+            const uint4 l0 = ring_line(lane_off, vstored >> 2);
+            const uint4 l1 = ring_line(lane_off, (vstored >> 2) + 4);
+            uint8_t* const my_ptr = line0 + vstored;
+            const uint4 p1 = make_uint4(swap1(l1.x), swap1(l1.y), swap1(l1.z), swap1(l1.w));
+            const uint32_t p_lo = swap1((uint32_t)reinterpret_cast<uintptr_t>(my_ptr));
+            const uint32_t p_hi = swap1((uint32_t)(reinterpret_cast<uintptr_t>(my_ptr) >> 32));
+            const bool p_coop = swap1(coop ? 1u : 0u) != 0;
+            uint8_t* const p_ptr = reinterpret_cast<uint8_t*>(((uintptr_t)p_hi << 32) | p_lo);
 #pragma unroll
-                for (int par = 0; par < 2; par++) {
-                    const bool owner = (lane & 1) == par;
-                    if (owner ? coop : p_coop) {
-                        const uint32_t w = owner ? my_w : p_w + 4;
-                        const uint32_t sl = owner ? lane_off : (lane_off ^ 1u);
-                        uint4 q;
-                        q.x = oring[seg_slot(sl, w + 0)];
-                        q.y = oring[seg_slot(sl, w + 1)];
-                        q.z = oring[seg_slot(sl, w + 2)];
-                        q.w = oring[seg_slot(sl, w + 3)];
-                        *reinterpret_cast<uint4*>(owner ? my_ptr : p_ptr + 16) = q;
-                    }
-                }
+            for (int par = 0; par < 2; par++) {
+                const bool owner = (lane & 1) == par;
+                // (component-wise opaque selects: a select between two uint4 would become a scratch array)
+                const uint4 q = make_uint4(vsel(owner, l0.x, p1.x), vsel(owner, l0.y, p1.y), vsel(owner, l0.z, p1.z),
+                                           vsel(owner, l0.w, p1.w));
+                if (owner ? coop : p_coop) *reinterpret_cast<uint4*>(owner ? my_ptr : p_ptr + 16) = q;
             }
             if (single || pair) {
-                store_piece(vstored, coop);
+                account_piece(l0, vstored, coop);
                 vstored += 16;
             }
             if (pair) {
-                store_piece(vstored, coop);
+                account_piece(l1, vstored, coop);
                 vstored += 16;
             }
         }
@@ -898,29 +987,30 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     // A long dist-1 run (src/decompress.rs:793-801 fills it with one byte): bring the lane to a
     // 16-B line boundary through the ring, then store whole lines of the byte directly; their
     // Adler-32 contribution has a closed form.
+    uint32_t bulk_lines = 0, bulk_c4 = 0;
+    uint8_t* bulk_dst = nullptr;
     auto bulk_fill = [&](uint32_t c) __attribute__((always_inline)) {
         const uint32_t c4 = c * 0x01010101u;
         // complete the accumulator, then whole words up to the line boundary
-        acc |= c4 << sh;
-        oring[seg_slot(lane_off, vposw)] = acc;
-        vposw++;
-        fill -= 4 - (sh >> 3);
-        acc = 0;
-        sh = 0;
-        while (vposw & 3) {
-            oring[seg_slot(lane_off, vposw)] = c4;
-            vposw++;
+        wr.acc |= c4 << wr.sh;
+        oring[seg_slot(lane_off, wr.vposw)] = wr.acc;
+        wr.vposw++;
+        fill -= 4 - (wr.sh >> 3);
+        wr.acc = 0;
+        wr.sh = 0;
+        while (wr.vposw & 3) {
+            oring[seg_slot(lane_off, wr.vposw)] = c4;
+            wr.vposw++;
             fill -= 4;
         }
-        while (4 * vposw != vstored) {  // the complete lines waiting in the ring
+        while (4 * wr.vposw != vstored) {  // the complete lines waiting in the ring
             store_piece(vstored);
             vstored += 16;
         }
-        uint32_t lines = min(fill, vend - vstored) >> 4;
-        const uint32_t m = lines << 4;
-        const uint4 q = make_uint4(c4, c4, c4, c4);
-        uint8_t* dst = line0 + vstored;
-        for (; lines; lines--, dst += 16) *reinterpret_cast<uint4*>(dst) = q;
+        bulk_lines = min(fill, vend - vstored) >> 4;
+        const uint32_t m = bulk_lines << 4;
+        bulk_dst = line0 + vstored;
+        bulk_c4 = c4;
         // m bytes of value c: a' = a + m c ; b' = b + m a + c m (m + 1) / 2
         ad_a %= kAdlerMod;
         ad_b %= kAdlerMod;
@@ -929,8 +1019,26 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
         ad_b = (uint32_t)((ad_b + (uint64_t)(m % kAdlerMod) * ad_a + tri * c) % kAdlerMod);
         ad_a = (uint32_t)((ad_a + (uint64_t)m * c) % kAdlerMod);
         vstored += m;
-        vposw += m >> 2;
+        wr.vposw += m >> 2;
         fill -= m;
+    };
+    // ... and the lines themselves are stored by the whole wavefront, one lane's run after the
+    // other, 64 lines (1 KiB, coalesced) per instruction: a stream of long runs is decoded by a
+    // handful of lanes, which would otherwise store their KiBs line by line on their own.
+    auto bulk_store = [&]() __attribute__((always_inline)) {
+        uint64_t todo = __ballot(bulk_lines != 0);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t n_lines = __shfl(bulk_lines, src, kWave);
+            const uint32_t c4 = __shfl(bulk_c4, src, kWave);
+            const uint32_t d_lo = __shfl((uint32_t)reinterpret_cast<uintptr_t>(bulk_dst), src, kWave);
+            const uint32_t d_hi = __shfl((uint32_t)(reinterpret_cast<uintptr_t>(bulk_dst) >> 32), src, kWave);
+            uint8_t* const dst = reinterpret_cast<uint8_t*>(((uintptr_t)uni(d_hi) << 32) | uni(d_lo));
+            const uint4 q = make_uint4(c4, c4, c4, c4);
+            for (uint32_t i = (uint32_t)lane; i < uni(n_lines); i += kWave) *reinterpret_cast<uint4*>(dst + 16 * (size_t)i) = q;
+        }
+        bulk_lines = 0;
     };
 
     SEGTIME(4);
@@ -939,71 +1047,103 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     const uint32_t ring_base = lds_offset(L.in_ring) + 4 * lane_off;
     const uint32_t out_base = lds_offset(L.out_ring) + 4 * lane_off;
     // A lane runs while pos < end2 or a run is being filled.
-    // Outer loop = input event + two x (drain + kSegSteps steps of <= 4 B each).
+    // Outer loop = input event + two x (drain + fast group + one general step).
+#ifdef FDH_DEBUG_TILES
+    uint32_t tq_ev = 0, tq_dr = 0, tq_grp = 0, tq_gen = 0, nq_gen = 0, nq_grp = 0;
+#define TQ(var, t0) var += (uint32_t)(clock64() - (t0))
+#define TQ0(name) const long long name = clock64()
+#else
+#define TQ(var, t0) do { } while (0)
+#define TQ0(name) do { } while (0)
+#endif
     while (__any(pos < end2 || fill != 0)) {
-        // one memory event per two groups of steps (as in the counting pass); the output side is
-        // drained before every group (<= 32 B are produced per group)
-        rd.events(pos < end2 || fill != 0, 2 * kSegNeed - 1);
-      for (int half = 0; half < 2; half++) {
-        drain();
-        if (__any(fill >= kSegBulkFill)) {
-            if (fill >= kSegBulkFill) bulk_fill(seg_lastlit(last_e));
-        }
-        uint32_t left = kSegSteps;
-        iter += kSegSteps;
-        while (left) {
-            if (!__any(fill != 0)) {  // nobody is filling a run: literal steps until a special entry turns up
-                SegWriter wr{acc, sh, vposw};
-                left = seg_write_group(left, end2, ring_base, out_base, rd, wr, pos, last_e);
-                acc = wr.acc;
-                sh = wr.sh;
-                vposw = wr.vposw;
-                if (left == 0) break;
+        TQ0(t_ev);
+        rd.events(pos < end2 || fill != 0, kSegEventNeed);
+        TQ(tq_ev, t_ev);
+        for (int half = 0; half < 2; half++) {
+            TQ0(t_dr);
+            drain();
+            if (__any(fill >= kSegBulkFill)) {
+                if (fill >= kSegBulkFill) bulk_fill(seg_lastlit(last_e));
+                bulk_store();
             }
-            left--;
-            {
+            TQ(tq_dr, t_dr);
+            TQ0(t_grp);
+            // fast group: lanes at least a group away from their end that are not filling a run
+            const bool fast = fill == 0 && pos + kSegGroupBits <= end2 && rd.level() >= kSegHalfNeed;
+            bool general = !fast && (fill != 0 || (pos < end2 && rd.level() >= 2));
+            if (__any(fast)) {
+                if (fast) {
+                    uint32_t eA, eB;
+                    const uint32_t b0 = rd.boff, r0 = rd.in_rd;
+                    seg_write_group(kSegPairs, ring_base, out_base, rd, wr, last_e, eA, eB);
+                    pos += 32 * (rd.in_rd - r0) + rd.boff - b0;
+                    last_e = seg_last_after_group(last_e, eA, eB);
+                    general = ((eA | eB) & SK_KIND) != 0;
+                }
+                iter += kSegSteps;
+#ifdef FDH_DEBUG_TILES
+                nq_grp++;
+#endif
+            }
+            TQ(tq_grp, t_grp);
+            TQ0(t_gen);
+            if (__any(general)) {
+#ifdef FDH_DEBUG_TILES
+                nq_gen++;
+#endif
                 // general step (selects only): a token of any kind, or 4 bytes of a run in progress
+                iter++;
                 const uint32_t win = rd.window();
-                const uint32_t e = lit[win & (kLitSize - 1)];
                 const uint32_t nw = rd.peek();
                 const bool filling = fill != 0;
-                const bool dec = !filling && pos < end2;  // this lane decodes a token now
-                const bool is_run = (e & SE_RUN) != 0;
-                const SegRun r = seg_run(e, win);
-                const uint32_t n8_lit = dec ? seg_n8(e) : 0u;
-                const bool bad_now = dec && ((e & (SE_BAD | SE_EOB)) != 0 || (is_run && (last_e == 0 || r.bad_dist)));
+                const bool can_dec = general && pos < end2;
+                const SegTok t = seg_token(lit, 0u, win, can_dec, false);
+                const bool is_run = t.run != 0;
+                // a run right behind a run goes on with the same byte: the lengths add up (a stream of
+                // long runs is then one bulk fill per token instead of a bulk fill and a few 4-byte steps)
+                const bool merge = filling && can_dec && is_run && !t.bad;
+                const bool dec = can_dec && (!filling || merge);  // this lane decodes a token now
+                const uint32_t n8_lit = (dec && !merge) ? t.n8 : 0u;
+                const bool bad_now = dec && (t.bad || t.eob || (is_run && last_e == 0));
                 bad2 = bad2 || bad_now;
-                last_e = n8_lit ? e : last_e;
-                const uint32_t nf = min(fill, 4u);
+                last_e = n8_lit ? t.e : last_e;
+                const bool emit = general && filling && !merge;
+                const uint32_t nf = emit ? min(fill, 4u) : 0u;
                 uint32_t vf = seg_lastlit(last_e) * 0x01010101u;
                 vf = nf < 4 ? (vf & ((1u << (8 * nf)) - 1)) : vf;
-                const uint32_t n8 = filling ? 8 * nf : n8_lit;
-                const uint32_t v = filling ? vf : (n8_lit ? e >> 16 : 0u);
-                fill = filling ? fill - nf : ((dec && is_run && !bad_now) ? r.length : 0u);
-                const uint32_t used = dec ? seg_used(e) : 0u;
+                const uint32_t n8 = emit ? 8 * nf : n8_lit;
+                const uint32_t v = emit ? vf : (n8_lit ? t.e >> 8 : 0u);
+                fill = merge ? fill + t.run : (filling ? fill - nf : ((dec && is_run && !bad_now) ? t.run : 0u));
+                const uint32_t used = dec ? t.used : 0u;
                 pos += used;
                 rd.advance(used, nw);
                 end2 = bad_now ? 0u : end2;
-                const uint64_t t = (uint64_t)v << sh;
-                acc |= (uint32_t)t;
+                const uint64_t tt = (uint64_t)v << wr.sh;
+                wr.acc |= (uint32_t)tt;
                 // the ring slot at vposw is always free: the (possibly partial) accumulator is
                 // written there every time and only counts once it is full
-                oring[seg_slot(lane_off, vposw)] = acc;
-                const uint32_t tot = sh + n8;
+                oring[seg_slot(lane_off, wr.vposw)] = wr.acc;
+                const uint32_t tot = wr.sh + n8;
                 const bool full = tot >= 32;
-                acc = full ? (uint32_t)(t >> 32) : acc;
-                vposw += full ? 1u : 0u;
-                sh = tot & 31;
+                wr.acc = full ? (uint32_t)(tt >> 32) : wr.acc;
+                wr.vposw += full ? 1u : 0u;
+                wr.sh = tot & 31;
             }
-        }
-      }
-        if (live && rd.starved()) {  // cannot happen (events() keeps the ring ahead); stop rather than decode garbage
-            bad2 = true;
-            end2 = 0;
-            fill = 0;
+            TQ(tq_gen, t_gen);
         }
     }
     (void)iter;
+#ifdef FDH_DEBUG_TILES
+    if (sid < 16 && lane == 0) {
+        g_segdbg2[sid * 8 + 0] = tq_ev;
+        g_segdbg2[sid * 8 + 1] = tq_dr;
+        g_segdbg2[sid * 8 + 2] = tq_grp;
+        g_segdbg2[sid * 8 + 3] = tq_gen;
+        g_segdbg2[sid * 8 + 4] = nq_grp;
+        g_segdbg2[sid * 8 + 5] = nq_gen;
+    }
+#endif
     SEGTIME(5);
     SEGDBG(4, iter);
     SEGDBG(7, total);
@@ -1011,8 +1151,8 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     drain_all();
     if (live) {
         // the loose bytes go into the ring as a final word; zero the rest of that 16-B line
-        oring[seg_slot(lane_off, vposw)] = acc;
-        for (uint32_t w = vposw + 1; (w & 3) != 0; w++) oring[seg_slot(lane_off, w)] = 0;
+        oring[seg_slot(lane_off, wr.vposw)] = wr.acc;
+        for (uint32_t w = wr.vposw + 1; (w & 3) != 0; w++) oring[seg_slot(lane_off, w)] = 0;
         if (vstored < vend) {
             store_piece(vstored);
             // the last line was summed as 16 bytes; it holds only 16 - z of ours followed by z zeros
@@ -1022,7 +1162,7 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
             ad_b = (ad_b + kAdlerMod - (uint32_t)(((uint64_t)z * ad_a) % kAdlerMod)) % kAdlerMod;
         }
     }
-    const bool wrong_count = live && (4 * vposw + (sh >> 3) != vend);
+    const bool wrong_count = live && (4 * wr.vposw + (wr.sh >> 3) != vend);
     {
         const uint64_t m_bad = __ballot(bad2), m_wrong = __ballot(wrong_count);
         (void)m_bad;

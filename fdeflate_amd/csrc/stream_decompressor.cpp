@@ -1,0 +1,205 @@
+// stream_decompressor.cpp -- `Decompressor::read` (reference src/decompress.rs:158-337) on top of
+// the batch engine.
+//
+// The reference decoder is resumable at any input / output split (State :84-93, BitBuffer,
+// QueuedOutput :1067-1070).  The GPU engine is one-shot, so this object keeps the streaming
+// CONTRACT on the host and lets the device do every bit of decoding:
+//
+//   * input handed to `read` is appended to a device-resident copy of the stream (consumed =
+//     input_len, always: "the input is fully consumed" is the post-condition we pick);
+//   * the stream-so-far is decoded by fdh_inflate_batch (batch of one) into a device slot whose
+//     capacity is exactly what the caller can take now (bytes delivered so far + the room left in
+//     `output`), so the one-shot classification (src/decompress.rs:1126-1139) says which
+//     post-condition holds: Ok -> done; OutputTooLarge -> "the output is full but there are more
+//     bytes"; InsufficientInput -> the engine reports how many bytes the reference had produced when
+//     it ran dry, and exactly those are delivered;
+//   * only output[output_position ..] is written, never more than the room, and the bytes in
+//     front of output_position are not needed (each attempt decodes from the start of the stream,
+//     the LZ77 history lives in the device slot).
+//
+// Re-decoding the prefix on every call would be quadratic for a large stream fed in small pieces;
+// above kAlwaysBelow buffered bytes an attempt is made only once the stream has grown by 1/8 --
+// or when the caller passes an empty `input`, which is how both the reference's test harness
+// (src/decompress/tests/test_utils.rs:70-74: chunk size 0 once the input is exhausted) and the png
+// crate's finish loop ask for whatever can still be produced.
+//
+// There is no CPU decode path here: without a GPU every call returns FDH_ERR_NO_DEVICE.
+#include "../../include/fdeflate_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+
+extern "C" void fdh_set_last_error(const char* msg);
+
+namespace {
+
+constexpr size_t kAlwaysBelow = 256 * 1024;
+
+struct DevBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    // grows to at least n bytes, keeping the first `keep` bytes
+    hipError_t reserve(size_t n, size_t keep) {
+        if (n <= cap) return hipSuccess;
+        size_t want = std::max(n, cap * 2);
+        want = std::max<size_t>(want, 4096);
+        uint8_t* q = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&q), want);
+        if (e != hipSuccess) return e;
+        if (keep) {
+            e = hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(q);
+                return e;
+            }
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
+};
+
+int fail(int code, const std::string& msg) {
+    fdh_set_last_error(msg.c_str());
+    return code;
+}
+
+}  // namespace
+
+struct fdh_decompressor {
+    DevBuf in, out, meta;
+    size_t in_len = 0;        // bytes of the stream on the device
+    size_t attempted_in = 0;  // in_len at the last decode attempt
+    size_t delivered = 0;     // output bytes handed to the caller so far
+    bool ignore_adler = false;
+    bool done = false;
+    bool output_limited = false;  // the last attempt stopped because the caller's buffer was full
+    bool tried = false;
+    uint32_t error = 0;       // sticky DecompressionError (status code), 0 = none
+    int device = 0;
+};
+
+extern "C" {
+
+fdh_decompressor* fdh_decompressor_new(void) {
+    fdh_decompressor* d = new (std::nothrow) fdh_decompressor();
+    if (d && hipGetDevice(&d->device) != hipSuccess) d->device = 0;
+    return d;
+}
+
+void fdh_decompressor_free(fdh_decompressor* d) { delete d; }
+
+void fdh_decompressor_ignore_adler32(fdh_decompressor* d) {
+    if (d) d->ignore_adler = true;
+}
+
+int fdh_decompressor_is_done(const fdh_decompressor* d) { return d && d->done ? 1 : 0; }
+
+int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t input_len, uint8_t* output,
+                          size_t output_len, size_t output_position, size_t* consumed, size_t* produced,
+                          uint32_t* stream_status) {
+    if (!d || !consumed || !produced || !stream_status) return fail(FDH_ERR_INVALID_ARGUMENT, "null pointer");
+    *consumed = 0;
+    *produced = 0;
+    *stream_status = FDH_STREAM_OK;
+    if (d->done) return FDH_SUCCESS;  // src/decompress.rs:185-187: (0, 0) once Done
+    if (output_position > output_len)  // the reference panics here (src/decompress.rs:189)
+        return fail(FDH_ERR_INVALID_ARGUMENT, "output_position is out of bounds");
+    if (d->error) {
+        *stream_status = d->error;
+        return FDH_SUCCESS;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? FDH_ERR_OUT_OF_MEMORY : FDH_ERR_HIP,       \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+    int prev_dev = 0;
+    HIP_TRY(hipGetDevice(&prev_dev));
+    if (prev_dev != d->device) HIP_TRY(hipSetDevice(d->device));
+    struct Restore {
+        int dev, cur;
+        ~Restore() {
+            if (dev != cur) (void)hipSetDevice(dev);
+        }
+    } restore{prev_dev, d->device};
+
+    // take the input (the whole of it: that is the post-condition this implementation offers)
+    if (input_len) {
+        if (d->in_len + input_len >= (1ull << 31)) return fail(FDH_ERR_INVALID_ARGUMENT, "stream too large (>= 2 GiB)");
+        HIP_TRY(d->in.reserve(d->in_len + input_len + 16, d->in_len));
+        HIP_TRY(hipMemcpy(d->in.p + d->in_len, input, input_len, hipMemcpyHostToDevice));
+        d->in_len += input_len;
+    }
+    *consumed = input_len;
+
+    const size_t room = output_len - output_position;
+    // is a decode attempt worth it?  (nothing new and not output-limited -> no)
+    const bool grew = d->in_len != d->attempted_in;
+    const bool flush = input_len == 0;
+    bool attempt = !d->tried || d->output_limited || (grew && (flush || d->in_len < kAlwaysBelow ||
+                                                               d->in_len >= d->attempted_in + d->attempted_in / 8));
+    if (d->tried && d->output_limited && room == 0) attempt = false;  // still nowhere to put a byte
+    if (!attempt) return FDH_SUCCESS;
+
+    size_t cap = d->delivered + room;
+    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    HIP_TRY(d->out.reserve(cap + 16, 0));
+    HIP_TRY(d->meta.reserve(64, 0));
+    uint64_t meta[8] = {0, (uint64_t)d->in_len, 0, (uint64_t)cap, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(d->meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
+    uint64_t* m = reinterpret_cast<uint64_t*>(d->meta.p);
+    uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
+    // a hipMalloc'd buffer can be empty only before the first byte arrives
+    HIP_TRY(d->in.reserve(16, d->in_len));
+    int rc = fdh_inflate_batch(d->in.p, m, d->out.p, m + 2, res, res + 1, res + 2, 1,
+                               d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u, nullptr);
+    if (rc != FDH_SUCCESS) return rc;
+    uint32_t host_res[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost));  // synchronises the null stream
+    const uint32_t st = host_res[1];
+    d->tried = true;
+    d->attempted_in = d->in_len;
+    d->output_limited = false;
+    size_t have = 0;  // valid prefix of the decoded stream in the device slot
+    if (st == FDH_STREAM_OK || st == FDH_WRONG_CHECKSUM || st == FDH_OUTPUT_TOO_LARGE || st == FDH_INSUFFICIENT_INPUT) {
+        have = std::min<size_t>(host_res[0], cap);
+    }
+    if (have > d->delivered) {
+        const size_t n = have - d->delivered;  // <= room by construction
+        HIP_TRY(hipMemcpy(output + output_position, d->out.p + d->delivered, n, hipMemcpyDeviceToHost));
+        d->delivered = have;
+        *produced = n;
+    }
+    switch (st) {
+        case FDH_STREAM_OK:
+            d->done = true;
+            break;
+        case FDH_OUTPUT_TOO_LARGE:
+            d->output_limited = true;  // "the output is full but there are more bytes to output"
+            break;
+        case FDH_INSUFFICIENT_INPUT:
+            break;                     // Ok with is_done() == false: wait for more input
+        default:
+            d->error = st;             // a DecompressionError: sticky, like the reference's poisoned state
+            *stream_status = st;
+            break;
+    }
+    return FDH_SUCCESS;
+#undef HIP_TRY
+}
+
+}  // extern "C"

@@ -27,10 +27,11 @@ def gather_metadata(status, out_len, adler, group=None):
     return out
 
 
-def gather_payload(out, group=None):
-    """Optional payload gather (link-bound over xGMI: timed separately by the bench)."""
+def gather_payload(out, group=None, into=None):
+    """Optional payload gather (link-bound over xGMI: timed separately by the bench).  `into`
+    reuses a [world, ...] buffer from an earlier call."""
     world = dist.get_world_size(group)
-    full = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=out.device)
+    full = into if into is not None else torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=out.device)
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(full, out.contiguous(), group=group)
     else:

@@ -83,8 +83,10 @@ enum {
  *   in, in_off[n+1]    packed compressed bytes; stream i = in[in_off[i] .. in_off[i+1])
  *   out, out_off[n+1]  output slots; capacity of stream i = out_off[i+1] - out_off[i]
  *                      (< 4 GiB); bytes outside [out_off[i], out_off[i+1]) are never written
- *   out_len[n]         decoded length (on FDH_OUTPUT_TOO_LARGE: the capacity, slot holds the
- *                      partial output like `partial_output`); unspecified for other errors
+ *   out_len[n]         decoded length; on FDH_OUTPUT_TOO_LARGE the capacity (the slot holds the
+ *                      partial output like `partial_output`); on FDH_INSUFFICIENT_INPUT the bytes
+ *                      `Decompressor::read` had produced when the input ran out (they are in the
+ *                      slot); unspecified for other errors
  *   status[n]          per-stream status (above)
  *   adler[n]           Adler-32 of the decoded bytes (nullable)
  *   flags              FDH_FLAG_*
@@ -123,6 +125,36 @@ int fdh_deflate_stored_batch(const uint8_t *in, const uint64_t *in_off, uint8_t 
                              void *hip_stream);
 /* Exact size of the level-0 stream of a `len`-byte buffer. */
 uint64_t fdh_stored_size(uint64_t len);
+
+/* ---- streaming decoder: `Decompressor` (src/decompress.rs:96-156, 179-342) ----------------
+ * A host-side object with exactly `Decompressor::read`'s contract on HOST buffers; every bit of
+ * decoding is done by fdh_inflate_batch on the device (the object keeps a device-resident copy of
+ * the stream so far and a device output slot; see csrc/stream_decompressor.cpp).
+ *
+ *   fdh_decompressor_new            Decompressor::new()            src/decompress.rs:123
+ *   fdh_decompressor_ignore_adler32 Decompressor::ignore_adler32() src/decompress.rs:154
+ *   fdh_decompressor_is_done        Decompressor::is_done()        src/decompress.rs:340
+ *   fdh_decompressor_read           Decompressor::read(input, output, output_position)
+ *                                   -> Result<(consumed, produced), DecompressionError>
+ *                                                                  src/decompress.rs:179-337
+ * `read` writes only output[output_position .. output_position + *produced); bytes in front of
+ * output_position are never read or written.  When it returns FDH_SUCCESS with *stream_status ==
+ * FDH_STREAM_OK at least one of the reference's post-conditions holds (src/decompress.rs:167-170):
+ * the input is fully consumed (always: *consumed == input_len), the output is full but there are
+ * more bytes, or the stream is complete (is_done).  Once done, read returns (0, 0)
+ * (src/decompress.rs:185-187).  A `DecompressionError` is reported in *stream_status (1 + ordinal)
+ * and is sticky.  An EMPTY input asks for whatever can still be produced from the bytes already
+ * handed over (how the reference's own test harness, src/decompress/tests/test_utils.rs:70-74, and
+ * the png crate finish a stream).  Function return = infrastructure status as everywhere else.
+ * `output_position > output_len` (a panic in the reference, :189) is FDH_ERR_INVALID_ARGUMENT. */
+typedef struct fdh_decompressor fdh_decompressor;
+fdh_decompressor *fdh_decompressor_new(void);
+void fdh_decompressor_free(fdh_decompressor *d);
+void fdh_decompressor_ignore_adler32(fdh_decompressor *d);
+int fdh_decompressor_is_done(const fdh_decompressor *d);
+int fdh_decompressor_read(fdh_decompressor *d, const uint8_t *input, size_t input_len,
+                          uint8_t *output, size_t output_len, size_t output_position,
+                          size_t *consumed, size_t *produced, uint32_t *stream_status);
 
 /* ---- single-buffer conveniences on HOST memory (names mirror src/lib.rs:29-36) ---------
  * Each stages through the device (H2D, batch of one, D2H) and synchronises.  Results are

@@ -1521,10 +1521,19 @@ static void run_batch(BatchJob *job, int nthreads) {
         return;
     }
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
-    for (int t = 0; t < nthreads; t++) {
-        pthread_create(&th[t], NULL, batch_worker, job);
+    int started = 0;
+    if (th) {
+        for (int t = 0; t < nthreads; t++) {
+            if (pthread_create(&th[started], NULL, batch_worker, job) != 0) {
+                break; /* fewer threads than asked for: the ones that exist share the work */
+            }
+            started++;
+        }
     }
-    for (int t = 0; t < nthreads; t++) {
+    if (started == 0) {
+        batch_worker(job);
+    }
+    for (int t = 0; t < started; t++) {
         pthread_join(th[t], NULL);
     }
     free(th);
@@ -1544,4 +1553,118 @@ void fdo_deflate_ultrafast_batch(const uint8_t *in, const uint64_t *in_off, uint
     ensure_tables();
     BatchJob job = {in, in_off, out, out_off, out_len, NULL, NULL, n, 0, 1, NULL};
     run_batch(&job, nthreads);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Timed CPU baseline (bench.py cpu_baseline leg)                             */
+/* ------------------------------------------------------------------------- */
+/* Threads are created ONCE; thread t decodes streams t, t+T, t+2T, ... of the sample `passes`
+ * times, so thread start-up is outside the measurement (first barrier) and every thread has
+ * passes * n / T streams of work.  kind 0 = this oracle (the port of the reference algorithm),
+ * kind 1 = system zlib `uncompress` (second comparator). */
+#include <time.h>
+#include <zlib.h>
+
+typedef struct {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    uint8_t *out;
+    const uint64_t *out_off;
+    uint64_t n;
+    int kind, passes, nthreads;
+    pthread_barrier_t *bar;
+    uint64_t *errors;
+} TimedShared;
+
+typedef struct {
+    TimedShared *sh;
+    int tid;
+} TimedArg;
+
+static void *timed_worker(void *arg) {
+    TimedArg *ta = (TimedArg *)arg;
+    TimedShared *j = ta->sh;
+    uint64_t bad = 0;
+    pthread_barrier_wait(j->bar); /* start line */
+    for (int p = 0; p < j->passes; p++) {
+        for (uint64_t i = (uint64_t)ta->tid; i < j->n; i += (uint64_t)j->nthreads) {
+            const uint8_t *src = j->in + j->in_off[i];
+            size_t src_len = (size_t)(j->in_off[i + 1] - j->in_off[i]);
+            uint8_t *dst = j->out + j->out_off[i];
+            size_t cap = (size_t)(j->out_off[i + 1] - j->out_off[i]);
+            if (j->kind == 0) {
+                size_t n = 0;
+                uint32_t ad = 0;
+                int st = fdo_decompress_bounded(src, src_len, dst, cap, &n, 0, &ad);
+                bad += (st != FDO_OK);
+            } else {
+                uLongf dl = (uLongf)cap;
+                bad += (uncompress(dst, &dl, src, (uLong)src_len) != Z_OK);
+            }
+        }
+    }
+    pthread_barrier_wait(j->bar); /* finish line */
+    __atomic_fetch_add(j->errors, bad, __ATOMIC_RELAXED);
+    return NULL;
+}
+
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* Returns the seconds between the start and the finish line, < 0 on failure (threads could not be
+ * created / streams failed to decode). */
+double fdo_timed_inflate(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
+                         const uint64_t *out_off, uint64_t n, int nthreads, int passes, int kind) {
+    ensure_tables();
+    if (nthreads < 1) {
+        nthreads = 1;
+    }
+    pthread_barrier_t bar;
+    uint64_t errors = 0;
+    if (pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1) != 0) {
+        return -1.0;
+    }
+    TimedShared sh = {in, in_off, out, out_off, n, kind, passes, nthreads, &bar, &errors};
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    TimedArg *args = (TimedArg *)malloc(sizeof(TimedArg) * (size_t)nthreads);
+    if (!th || !args) {
+        free(th);
+        free(args);
+        pthread_barrier_destroy(&bar);
+        return -1.0;
+    }
+    int started = 0;
+    for (int t = 0; t < nthreads; t++) {
+        args[t].sh = &sh;
+        args[t].tid = t;
+        if (pthread_create(&th[t], NULL, timed_worker, &args[t]) != 0) {
+            break;
+        }
+        started++;
+    }
+    double dt = -1.0;
+    if (started == nthreads) {
+        pthread_barrier_wait(&bar);
+        double t0 = now_seconds();
+        pthread_barrier_wait(&bar);
+        dt = now_seconds() - t0;
+    } else {
+        /* cannot release a barrier sized for more threads than exist: cancel the ones waiting */
+        for (int t = 0; t < started; t++) {
+            pthread_cancel(th[t]);
+        }
+    }
+    for (int t = 0; t < started; t++) {
+        pthread_join(th[t], NULL);
+    }
+    free(th);
+    free(args);
+    pthread_barrier_destroy(&bar);
+    if (errors != 0) {
+        return -2.0;
+    }
+    return dt;
 }

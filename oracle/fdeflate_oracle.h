@@ -120,6 +120,12 @@ void fdo_deflate_ultrafast_batch(const uint8_t *in, const uint64_t *in_off, uint
                                  const uint64_t *out_off, uint32_t *out_len, uint64_t n,
                                  int nthreads);
 
+/* Timed CPU baseline: threads created once, thread t decodes streams t, t+T, ... `passes` times;
+ * returns the seconds between start and finish barrier (< 0: failure).  kind 0 = this oracle,
+ * kind 1 = system zlib `uncompress` (second comparator). */
+double fdo_timed_inflate(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
+                         const uint64_t *out_off, uint64_t n, int nthreads, int passes, int kind);
+
 #ifdef __cplusplus
 }
 #endif

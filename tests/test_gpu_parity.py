@@ -499,3 +499,105 @@ def test_batch_roundtrip_at_scale(harness):
     tr = comp[idx].to(torch.int64)
     trailer = (tr[:, 0] << 24) | (tr[:, 1] << 16) | (tr[:, 2] << 8) | tr[:, 3]
     assert torch.equal(trailer, adler.to(torch.int64) & 0xFFFFFFFF)
+
+
+def _roundtrip_at_scale(n, first, dev="cuda", sample=()):
+    """encode n x 64 KiB on the GPU, decode on the GPU, property checks at full size: every
+    stream Ok, lengths exact, decoded == raw, reported Adler-32 == the trailer the encoder wrote
+    (a checksum of checksums); the oracle byte-compares a strided sample of the COMPRESSED and of
+    the DECODED streams."""
+    import torch
+    import fdeflate_amd as fd
+    from fdeflate_amd import synth
+    L = 65536
+    raw = synth.gen_batch_torch(first, n, L, device=dev)
+    r_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    bound = (fd.ultrafast_bound(L) + 15) & ~15
+    # lengths first (bound-sized slots in chunks), then the packed 16-B aligned layout of the bench
+    clen = torch.empty(n, dtype=torch.int32, device=dev)
+    chunk = 8192
+    tmp = torch.empty(chunk * bound, dtype=torch.uint8, device=dev)
+    t_off = torch.arange(chunk + 1, dtype=torch.int64, device=dev) * bound
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        fd.deflate_ultrafast_batch(raw[c0:c1].reshape(-1), r_off[:c1 - c0 + 1], tmp, t_off[:c1 - c0 + 1], clen[c0:c1])
+    del tmp
+    clen64 = clen.to(torch.int64)
+    c_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    c_off[1:] = torch.cumsum((clen64 + 15) & ~15, 0)
+    comp = torch.zeros(int(c_off[-1]), dtype=torch.uint8, device=dev)
+    clen2 = fd.deflate_ultrafast_batch(raw.view(-1), r_off, comp, c_off)
+    assert torch.equal(clen2, clen)
+    out = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    out_len, status, adler = fd.inflate_batch(comp, c_off, out, r_off)
+    torch.cuda.synchronize(dev)
+    assert int(status.abs().sum()) == 0
+    assert bool((out_len == L).all())
+    assert torch.equal(out, raw.view(-1))
+    idx = (c_off[:-1] + clen64)[:, None] + torch.arange(-4, 0, device=dev)[None, :]
+    tr = comp[idx].to(torch.int64)
+    trailer = (tr[:, 0] << 24) | (tr[:, 1] << 16) | (tr[:, 2] << 8) | tr[:, 3]
+    assert torch.equal(trailer, adler.to(torch.int64) & 0xFFFFFFFF)
+    c_off_h = c_off.cpu().numpy()
+    clen_h = clen.cpu().numpy()
+    for i in sample:
+        r = raw[i].cpu().numpy().tobytes()
+        assert r == synth.gen_stream_np(first + i, L).tobytes()
+        got = comp[int(c_off_h[i]):int(c_off_h[i]) + int(clen_h[i])].cpu().numpy().tobytes()
+        assert got == ob.compress_ultra_fast(r), i
+        st, dec, ad = ob.decompress_bounded(got, L)
+        assert st == 0 and dec == out[i * L:(i + 1) * L].cpu().numpy().tobytes(), i
+        assert ad == (int(adler[i]) & 0xFFFFFFFF)
+
+
+def test_c2_full_size_batch(harness):
+    """BASELINE config 2 at full size: 65 536 x 64 KiB through fdh_inflate_batch."""
+    _roundtrip_at_scale(65536, 0, sample=range(0, 65536, 4099))
+
+
+def test_c4_one_shard_of_the_million_stream_batch(harness):
+    """BASELINE config 4 shards 1 048 576 streams over 8 GPUs: 131 072 streams per GPU (~4 GiB in,
+    8 GiB out).  One such shard (rank 3's seeds) on this GPU."""
+    _roundtrip_at_scale(131072, 3 * 131072, sample=range(5, 131072, 16381))
+
+
+def test_mixed_batch_on_every_visible_device(harness):
+    """BASELINE config 5's workload placed on cuda:k for every visible device while cuda:0 stays
+    the current device (the entry points make the tensors' device current for the call)."""
+    import torch
+    import fdeflate_amd as fd
+    pool = []
+    for name, comp, raw in streams.valid_streams():
+        pool.append((comp, len(raw) + 3))
+    for name, comp in streams.corpus_streams():
+        pool.append((comp, 1 << 16))
+    for item in streams.error_streams():
+        pool.append((item[1], 4096))
+    blobs = [p[0] for p in pool]
+    caps = [p[1] for p in pool]
+    rs, rl, ra, ro = harness.oracle_inflate(blobs, caps)
+    buf, in_off = streams.pack_exact(blobs)
+    out_off = np.zeros(len(blobs) + 1, dtype=np.int64)
+    out_off[1:] = np.cumsum(np.asarray(caps, dtype=np.int64))
+    torch.cuda.set_device(0)
+    for k in range(torch.cuda.device_count()):
+        dev = torch.device("cuda", k)
+        d_in = torch.from_numpy(buf).to(dev)
+        d_in_off = torch.from_numpy(in_off.astype(np.int64)).to(dev)
+        d_out = torch.zeros(int(out_off[-1]), dtype=torch.uint8, device=dev)
+        d_out_off = torch.from_numpy(out_off).to(dev)
+        out_len, status, adler = fd.inflate_batch(d_in, d_in_off, d_out, d_out_off)
+        torch.cuda.synchronize(dev)
+        assert torch.cuda.current_device() == 0
+        st = status.cpu().numpy().view(np.uint32)
+        ln = out_len.cpu().numpy().view(np.uint32)
+        h = d_out.cpu().numpy()
+        for i in range(len(blobs)):
+            assert int(st[i]) == rs[i], (k, i)
+            if rs[i] in (0, 17):
+                assert int(ln[i]) == rl[i] and h[out_off[i]:out_off[i] + rl[i]].tobytes() == ro[i], (k, i)
+    if torch.cuda.device_count() > 1:
+        a = torch.zeros(16, dtype=torch.uint8, device="cuda:0")
+        b = torch.zeros(2, dtype=torch.int64, device="cuda:1")
+        with pytest.raises(ValueError):
+            fd.inflate_batch(a, b, a, b)

@@ -6,7 +6,7 @@
 # profiles/<tag>_*.csv / .json.
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 20 --warmup 5 --no-cpu-baseline --no-also}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
