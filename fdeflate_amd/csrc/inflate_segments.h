@@ -73,6 +73,7 @@ constexpr uint32_t kNoByte = 0x100;  // "no literal seen yet"
 // this in the ring a pair of chunks fits, so waiting for the pair in flight gets the lane there.
 constexpr uint32_t kSegEventNeed = kSegInWords - 2 * kSegChunk;
 static_assert(kSegHalfNeed <= kSegEventNeed, "one half must be able to run right after an event");
+static_assert((2 * kSegGroupBits + kSegTokenBits + 31) / 32 + 1 <= kSegEventNeed, "a double group + a general step fit what an event guarantees");
 
 // Table entry of this kernel (built from the device layout of inflate_tables.h while staging):
 //   byte 0    [3:0] stream bits of the whole step, [5:4] literals of the step (1..3), [7:6] kind
@@ -604,17 +605,23 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
     if (s.pos < lim) rd.refill_now();
     while (__any(s.pos < lim)) {
         rd.events(s.pos < lim, kSegEventNeed);
-        for (int half = 0; half < 2; half++) {
+        {
             // a fast group must stay inside the lane's range and inside the stream, and needs its
-            // input in the ring (a lane that is short of input sits this half out: rare, dense data)
-            const bool fast = s.pos + kSegGroupBits <= min(lim, limit) && rd.level() >= kSegHalfNeed;
+            // input in the ring (a lane that is short of input sits this round out: rare, dense data).
+            // Nothing is drained in this pass, so one event serves a group of twice the steps (or,
+            // for the lanes close to their end, one of the usual size).
+            const uint32_t room = min(lim, limit);
+            const bool f2 = s.pos + 2 * kSegGroupBits <= room && rd.level() >= kSegEventNeed;
+            const bool f1 = s.pos + kSegGroupBits <= room && rd.level() >= kSegHalfNeed;
+            const uint32_t pairs = __any(f2) ? 2 * kSegPairs : kSegPairs;
+            const bool fast = pairs == kSegPairs ? f1 : f2;
             bool general = s.pos < lim && !fast && rd.level() >= 2;
             if (__any(fast)) {
                 iter += (uint32_t)__popcll(__ballot(fast)) << 16;
                 if (fast) {
                     uint32_t cnt16 = 0, eA, eB;
                     const uint32_t b0 = rd.boff, r0 = rd.in_rd;
-                    seg_count_group(kSegPairs, ring_base, rd, cnt16, s.last_e, eA, eB);
+                    seg_count_group(pairs, ring_base, rd, cnt16, s.last_e, eA, eB);
                     s.pos += 32 * (rd.in_rd - r0) + rd.boff - b0;
                     s.count8 += cnt16 >> 1;
                     s.last_e = seg_last_after_group(s.last_e, eA, eB);
@@ -622,15 +629,17 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
                 }
                 iter += 1u << 8;
             }
-            if (__any(general)) {
-                // general step (selects only): a token of any kind
+            // general step (selects only): a token of any kind.  Returns the lanes that took a run of
+            // the maximal length and sit on another run token (a flat stretch is a chain of maximal
+            // runs): for those the step is repeated at once instead of costing a whole half each.
+            auto general_step = [&](bool take) __attribute__((always_inline)) {
                 iter++;
                 const uint32_t win = rd.window();
                 const uint32_t nw = rd.peek();
-                const SegTok t = seg_token(lit, 0u, win, general, false);
+                const SegTok t = seg_token(lit, 0u, win, take, false);
                 const bool fault = t.bad || s.pos + t.used > limit;
-                const bool step = general && !fault && !t.eob;
-                const bool halt = general && !step;
+                const bool step = take && !fault && !t.eob;
+                const bool halt = take && !step;
                 s.stop = halt ? (fault ? 2u : 1u) : s.stop;
                 s.eob_bits = halt ? t.used : s.eob_bits;
                 lim = halt ? 0u : lim;
@@ -639,6 +648,14 @@ __device__ __forceinline__ uint32_t seg_count_scan(const uint32_t* lit, SegReade
                 const uint32_t adv = step ? t.used : 0u;
                 s.pos += adv;
                 rd.advance(adv, nw);
+                return step && t.run == 258 && s.pos < lim && rd.level() >= 2;
+            };
+            if (__any(general)) {
+                bool again = general_step(general);
+                for (int rep = 0; rep < 16 && __any(again); rep++) {
+                    again = again && (lit[rd.window() & (kLitSize - 1)] & SK_KIND) == SK_RUN;
+                    if (__any(again)) again = general_step(again);
+                }
             }
         }
     }
@@ -1042,7 +1059,14 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
     };
 
     SEGTIME(4);
+#ifdef FDH_DEBUG_TILES
+    const long long t_start0 = clock64();
+#endif
     if (live) rd.start(in, seg_bit0 + pos);
+#ifdef FDH_DEBUG_TILES
+    const uint32_t tq_start = (uint32_t)(clock64() - t_start0);
+    const long long t_loop0 = clock64();
+#endif
     uint32_t iter = 0;
     const uint32_t ring_base = lds_offset(L.in_ring) + 4 * lane_off;
     const uint32_t out_base = lds_offset(L.out_ring) + 4 * lane_off;
@@ -1088,27 +1112,30 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
             }
             TQ(tq_grp, t_grp);
             TQ0(t_gen);
-            if (__any(general)) {
+            // general step (selects only): a token of any kind, or 4 bytes of a run in progress.
+            // Returns the lanes that took / merged a run of the maximal length (what a longer run is cut
+            // into) and may sit on the next piece: for those the step is repeated at once (nothing is
+            // emitted in a repeat: a run right behind a run only adds to `fill`).
+            auto general_step = [&](bool take) __attribute__((always_inline)) {
 #ifdef FDH_DEBUG_TILES
                 nq_gen++;
 #endif
-                // general step (selects only): a token of any kind, or 4 bytes of a run in progress
                 iter++;
                 const uint32_t win = rd.window();
                 const uint32_t nw = rd.peek();
                 const bool filling = fill != 0;
-                const bool can_dec = general && pos < end2;
+                const bool can_dec = take && pos < end2;
                 const SegTok t = seg_token(lit, 0u, win, can_dec, false);
                 const bool is_run = t.run != 0;
                 // a run right behind a run goes on with the same byte: the lengths add up (a stream of
-                // long runs is then one bulk fill per token instead of a bulk fill and a few 4-byte steps)
+                // long runs is then one bulk fill for many tokens)
                 const bool merge = filling && can_dec && is_run && !t.bad;
                 const bool dec = can_dec && (!filling || merge);  // this lane decodes a token now
                 const uint32_t n8_lit = (dec && !merge) ? t.n8 : 0u;
                 const bool bad_now = dec && (t.bad || t.eob || (is_run && last_e == 0));
                 bad2 = bad2 || bad_now;
                 last_e = n8_lit ? t.e : last_e;
-                const bool emit = general && filling && !merge;
+                const bool emit = take && filling && !merge;
                 const uint32_t nf = emit ? min(fill, 4u) : 0u;
                 uint32_t vf = seg_lastlit(last_e) * 0x01010101u;
                 vf = nf < 4 ? (vf & ((1u << (8 * nf)) - 1)) : vf;
@@ -1129,6 +1156,14 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
                 wr.acc = full ? (uint32_t)(tt >> 32) : wr.acc;
                 wr.vposw += full ? 1u : 0u;
                 wr.sh = tot & 31;
+                return (merge || (dec && is_run && !bad_now)) && t.run == 258 && pos < end2 && rd.level() >= 2;
+            };
+            if (__any(general)) {
+                bool again = general_step(general);
+                for (int rep = 0; rep < 16 && __any(again); rep++) {
+                    again = again && (lit[rd.window() & (kLitSize - 1)] & SK_KIND) == SK_RUN;
+                    if (__any(again)) again = general_step(again);
+                }
             }
             TQ(tq_gen, t_gen);
         }
@@ -1142,6 +1177,8 @@ __device__ __forceinline__ void segments_write(const SegArgs& a, SegLds& L, cons
         g_segdbg2[sid * 8 + 3] = tq_gen;
         g_segdbg2[sid * 8 + 4] = nq_grp;
         g_segdbg2[sid * 8 + 5] = nq_gen;
+        g_segdbg2[sid * 8 + 6] = tq_start;
+        g_segdbg2[sid * 8 + 7] = (uint32_t)(clock64() - t_loop0);
     }
 #endif
     SEGTIME(5);

@@ -82,7 +82,8 @@ if hasattr(Lc, "fdh_debug_read_segtime"):
     d2 = dbg2.reshape(-1)
     for k in range(4):
         r = d2[8 * k: 8 * k + 8]
-        print("write pass stream %d: events %d, drain %d, groups %d (%d), general %d (%d) cycles" % (k, r[0], r[1], r[2], r[4], r[3], r[5]))
+        print("write pass stream %d: start %d, loop %d = events %d + drain %d + groups %d (%d) + general %d (%d) + other %d cycles"
+              % (k, r[6], r[7], r[0], r[1], r[2], r[4], r[3], r[5], int(r[7]) - int(r[0]) - int(r[1]) - int(r[2]) - int(r[3])))
     c = dbg[:4, 0]
     print("count scan: general steps %s, fast groups %s, fast lanes per group %s" % (c & 0xFF, (c >> 8) & 0xFF, (c >> 16) / np.maximum((c >> 8) & 0xFF, 1)))
     print("iterations (stream 0..3): count-scan %s window %s head %s recount %s rounds %s write %s"
