@@ -56,6 +56,14 @@ def lib():
     L.fdh_compress_to_vec_ultra_fast.restype = C.c_int
     L.fdh_compress_to_vec_ultra_fast.argtypes = [vp, sz, pp, C.POINTER(sz)]
     L.fdh_free.argtypes = [vp]
+    L.fdh_compress_bound.restype = u64
+    L.fdh_compress_bound.argtypes = [u64]
+    L.fdh_deflate_general_batch.restype = C.c_int
+    L.fdh_deflate_general_batch.argtypes = [vp, vp, vp, vp, vp, u64, u32, vp]
+    L.fdh_compress_to_vec.restype = C.c_int
+    L.fdh_compress_to_vec.argtypes = [vp, sz, pp, C.POINTER(sz)]
+    L.fdh_compress_to_vec_rle.restype = C.c_int
+    L.fdh_compress_to_vec_rle.argtypes = [vp, sz, pp, C.POINTER(sz)]
     L.fdh_decompressor_new.restype = vp
     L.fdh_decompressor_new.argtypes = []
     L.fdh_decompressor_free.argtypes = [vp]
@@ -77,6 +85,7 @@ EXPORTED_SYMBOLS = [
     "fdh_free", "fdh_stored_size", "fdh_deflate_stored_batch", "fdh_compress_to_vec_stored",
     "fdh_decompressor_new", "fdh_decompressor_free", "fdh_decompressor_ignore_adler32",
     "fdh_decompressor_is_done", "fdh_decompressor_read",
+    "fdh_compress_bound", "fdh_deflate_general_batch", "fdh_compress_to_vec", "fdh_compress_to_vec_rle",
 ]
 
 

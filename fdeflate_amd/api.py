@@ -156,6 +156,46 @@ def compress_to_vec_stored(data):
     return _take(out, n.value)
 
 
+def compress_to_vec(data):
+    """fdeflate::compress_to_vec (src/compress/mod.rs:294): level 1 in this snapshot."""
+    L = _lib.lib()
+    data = bytes(data)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    _lib.check(L.fdh_compress_to_vec(data, len(data), C.byref(out), C.byref(n)))
+    return _take(out, n.value)
+
+
+def compress_to_vec_rle(data):
+    """fdeflate::compress_to_vec_rle (src/compress/mod.rs:306)."""
+    L = _lib.lib()
+    data = bytes(data)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    _lib.check(L.fdh_compress_to_vec_rle(data, len(data), C.byref(out), C.byref(n)))
+    return _take(out, n.value)
+
+
+def compress_bound(n):
+    return int(_lib.lib().fdh_compress_bound(int(n)))
+
+
+MODE_LEVEL1 = 1
+MODE_RLE = 2
+
+
+def deflate_general_batch(raw, in_off, out, out_off, mode, out_len=None):
+    """Level-1 / RLE encode of n buffers, one stream per lane (fdh_deflate_general_batch)."""
+    import torch
+    n = in_off.numel() - 1
+    if out_len is None:
+        out_len = torch.empty(n, dtype=torch.int32, device=raw.device)
+    with _OnDevice(raw, in_off, out, out_off, out_len) as stream:
+        _lib.check(_lib.lib().fdh_deflate_general_batch(_ptr(raw), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                                       _ptr(out_len), n, mode, C.c_void_p(stream)))
+    return out_len
+
+
 def stored_size(n):
     return int(_lib.lib().fdh_stored_size(int(n)))
 

@@ -23,6 +23,11 @@ int fdh_launch_deflate_stored(const uint8_t* in, const uint64_t* in_off, uint8_t
                               uint32_t* out_len, uint64_t n, hipStream_t stream);
 int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                                  uint32_t* out_len, uint64_t n, hipStream_t stream);
+int fdh_launch_deflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                               uint32_t* out_len, uint64_t n, int rle, void* stream_work, void* wave_work, unsigned waves,
+                               hipStream_t stream);
+size_t fdh_deflate_general_stream_work_bytes(void);
+size_t fdh_deflate_general_wave_work_bytes(void);
 }
 
 namespace {
@@ -158,6 +163,56 @@ int fdh_debug_build_tables(const uint8_t* code_lengths320, uint32_t hlit, uint32
     return FDH_SUCCESS;
 }
 
+// ---- general encoder (level 1 / RLE): per-device workspace, grown on demand, never shrunk ----
+namespace {
+std::mutex g_gen_mutex;
+struct GenWork {
+    void* stream_work = nullptr;
+    void* wave_work = nullptr;
+    unsigned waves = 0;
+};
+GenWork g_gen_work[64];
+}  // namespace
+
+uint64_t fdh_compress_bound(uint64_t len) { return len + len / 2 + 1024; }
+
+int fdh_deflate_general_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                              uint32_t* out_len, uint64_t n, uint32_t mode, void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    if (!in_off || !out_off || !out_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
+    if (mode != FDH_MODE_LEVEL1 && mode != FDH_MODE_RLE) return fail(FDH_ERR_INVALID_ARGUMENT, "unknown encoder mode");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FDH_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    // one stream per lane: enough resident wavefronts to cover the batch, at most two per CU
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    unsigned waves = (unsigned)std::min<uint64_t>((n + 63) / 64, (uint64_t)2 * cus);
+    std::lock_guard<std::mutex> lock(g_gen_mutex);  // the workspace is shared by the calls on this device
+    GenWork& w = g_gen_work[dev];
+    if (w.waves < waves) {
+        HIP_TRY(hipDeviceSynchronize());  // nobody may still be using the old workspace
+        if (w.stream_work) (void)hipFree(w.stream_work);
+        if (w.wave_work) (void)hipFree(w.wave_work);
+        w = GenWork();
+        HIP_TRY(hipMalloc(&w.stream_work, (size_t)waves * 64 * fdh_deflate_general_stream_work_bytes()));
+        hipError_t e = hipMalloc(&w.wave_work, (size_t)waves * fdh_deflate_general_wave_work_bytes());
+        if (e != hipSuccess) {
+            (void)hipFree(w.stream_work);
+            w = GenWork();
+            return hip_fail(e, "hipMalloc(encoder workspace)");
+        }
+        w.waves = waves;
+    }
+    int rc = fdh_launch_deflate_general(in, in_off, out, out_off, out_len, n, mode == FDH_MODE_RLE, w.stream_work, w.wave_work,
+                                        waves, static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "general-encoder kernel launch");
+    // the workspace is per device, not per stream: calls are serialised by finishing this one
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    return FDH_SUCCESS;
+}
+
 // ---- single-buffer conveniences (host memory) --------------------------------------------
 
 // One decode of a host buffer into a device slot of `cap` bytes; the decoded (or partial) bytes
@@ -233,11 +288,12 @@ int fdh_decompress_to_vec(const uint8_t* input, size_t input_len, uint8_t** outp
     return inflate_growing(input, input_len, 0xFFFFFFF0ull, output, output_len, stream_status);
 }
 
-static int compress_one(bool stored, const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+static int compress_one(int kind, const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+    const bool stored = kind == 1;
     if (!output || !output_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null result pointer");
     if (input_len >= 0xFFFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "buffer too large (>= 4 GiB)");
     if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
-    size_t cap = (size_t)(stored ? fdh_stored_size(input_len) : fdh_ultrafast_bound(input_len));
+    size_t cap = (size_t)(stored ? fdh_stored_size(input_len) : (kind == 0 ? fdh_ultrafast_bound(input_len) : fdh_compress_bound(input_len)));
     DevBuf d_in, d_out, d_meta;
     HIP_TRY(d_in.alloc(input_len));
     HIP_TRY(d_out.alloc(cap));
@@ -247,8 +303,10 @@ static int compress_one(bool stored, const uint8_t* input, size_t input_len, uin
     HIP_TRY(hipMemcpy(d_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
     uint64_t* m = d_meta.as<uint64_t>();
     uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
-    int rc = stored ? fdh_deflate_stored_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr)
-                    : fdh_deflate_ultrafast_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr);
+    int rc = stored      ? fdh_deflate_stored_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr)
+             : kind == 0 ? fdh_deflate_ultrafast_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1, nullptr)
+                         : fdh_deflate_general_batch(d_in.as<uint8_t>(), m, d_out.as<uint8_t>(), m + 2, res, 1,
+                                                     kind == 2 ? FDH_MODE_LEVEL1 : FDH_MODE_RLE, nullptr);
     if (rc != FDH_SUCCESS) return rc;
     HIP_TRY(hipDeviceSynchronize());
     uint32_t n32 = 0;
@@ -269,11 +327,19 @@ static int compress_one(bool stored, const uint8_t* input, size_t input_len, uin
 }
 
 int fdh_compress_to_vec_ultra_fast(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
-    return compress_one(false, input, input_len, output, output_len);
+    return compress_one(0, input, input_len, output, output_len);
 }
 
 int fdh_compress_to_vec_stored(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
-    return compress_one(true, input, input_len, output, output_len);
+    return compress_one(1, input, input_len, output, output_len);
+}
+
+int fdh_compress_to_vec(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+    return compress_one(2, input, input_len, output, output_len);
+}
+
+int fdh_compress_to_vec_rle(const uint8_t* input, size_t input_len, uint8_t** output, size_t* output_len) {
+    return compress_one(3, input, input_len, output, output_len);
 }
 
 void fdh_free(void* p) { std::free(p); }

@@ -126,6 +126,26 @@ int fdh_deflate_stored_batch(const uint8_t *in, const uint64_t *in_off, uint8_t 
 /* Exact size of the level-0 stream of a `len`-byte buffer. */
 uint64_t fdh_stored_size(uint64_t len);
 
+/*
+ * fdh_deflate_general_batch -- the general encoder on `n` buffers, one stream per LANE, bit-exact:
+ *   FDH_MODE_LEVEL1  `compress_to_vec(input)` = `compress_to_vec_with_level(input, 1)`
+ *                    (src/compress/mod.rs:294-303; Compressor::new(.., 1, true) :69-101 =
+ *                    GreedyParser src/compress/parse/greedy.rs + HashTableMatchFinder
+ *                    src/compress/matchfinder/hashtable.rs, dynamic blocks src/compress/bitstream.rs)
+ *   FDH_MODE_RLE     `compress_to_vec_rle(input)` (src/compress/mod.rs:306-310; Compressor::new_rle
+ *                    :107-123 = RleParser src/compress/parse/rle.rs)
+ * Same argument convention as fdh_deflate_ultrafast_batch; slots of at least fdh_compress_bound(len_i)
+ * bytes; out_len[i] = 0xFFFFFFFF if a slot was too small or the buffer exceeds 1 GiB.  The call
+ * uses a per-device workspace (hash tables, symbol lists) and returns after the kernel has finished.
+ */
+#define FDH_MODE_LEVEL1 1u
+#define FDH_MODE_RLE 2u
+int fdh_deflate_general_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
+                              const uint64_t *out_off, uint32_t *out_len, uint64_t n, uint32_t mode,
+                              void *hip_stream);
+/* Slot size that always suffices for the general encoder: len + len / 2 + 1024. */
+uint64_t fdh_compress_bound(uint64_t len);
+
 /* ---- streaming decoder: `Decompressor` (src/decompress.rs:96-156, 179-342) ----------------
  * A host-side object with exactly `Decompressor::read`'s contract on HOST buffers; every bit of
  * decoding is done by fdh_inflate_batch on the device (the object keeps a device-resident copy of
@@ -168,6 +188,10 @@ int fdh_compress_to_vec_ultra_fast(const uint8_t *input, size_t input_len, uint8
                                    size_t *output_len); /* compress/mod.rs:313 */
 int fdh_compress_to_vec_stored(const uint8_t *input, size_t input_len, uint8_t **output,
                                size_t *output_len); /* compress_to_vec_with_level(.., 0), compress/mod.rs:299 */
+int fdh_compress_to_vec(const uint8_t *input, size_t input_len, uint8_t **output,
+                        size_t *output_len); /* compress_to_vec = level 1, compress/mod.rs:294 */
+int fdh_compress_to_vec_rle(const uint8_t *input, size_t input_len, uint8_t **output,
+                            size_t *output_len); /* compress_to_vec_rle, compress/mod.rs:306 */
 void fdh_free(void *p);
 
 /* ---- introspection ------------------------------------------------------------------- */

@@ -1668,3 +1668,739 @@ double fdo_timed_inflate(const uint8_t *in, const uint64_t *in_off, uint8_t *out
     }
     return dt;
 }
+
+/* ========================================================================= */
+/* General encoder, levels 1 ("fast") and RLE                                 */
+/*   Compressor            src/compress/mod.rs:47-217                         */
+/*   GreedyParser          src/compress/parse/greedy.rs:10-92                 */
+/*   RleParser             src/compress/parse/rle.rs:5-48                     */
+/*   ParserInner           src/compress/parse/mod.rs:18-181                   */
+/*   HashTableMatchFinder  src/compress/matchfinder/hashtable.rs:5-63         */
+/*   match_length/rle_match src/compress/matchfinder/mod.rs:42-145            */
+/*   write_block / build_huffman_tree  src/compress/bitstream.rs:41-325       */
+/*   BitWriter             src/compress/bitwriter.rs:3-51                     */
+/*                                                                            */
+/* PARITY PIN of this section: the reference holds no golden compressed bytes  */
+/* for these encoders (only round-trip tests, src/decompress.rs:1235-1259, and */
+/* the empty-input bytes 78 01 03 00 00 00 00 01, src/compress/mod.rs:71,      */
+/* 234-238), and it cannot be built here.  Pinned by restatement + the KAT +   */
+/* zlib round trips (tests/test_oracle_golden.py).  Two library behaviours the */
+/* reference inherits from Rust's std are restated as the std documents /      */
+/* implements them: BinaryHeap (rebuild, pop = sift_down_to_bottom + sift_up,  */
+/* PeekMut drop = sift_down) for tie-breaking in build_huffman_tree, and       */
+/* `sort_unstable_by_key` in the length-limiting branch, which is an insertion */
+/* sort (hence stable) for the <= 20-element code-length alphabet; for the     */
+/* 286 / 30-element alphabets that branch needs a code deeper than 15 bits and */
+/* its tie order is implementation-defined in the reference itself -- a stable */
+/* order is used here.                                                        */
+/* ========================================================================= */
+
+typedef struct {
+    uint64_t buffer;
+    uint8_t nbits;
+    uint8_t *out;
+    size_t cap, pos;
+    int overflow;
+} GBitWriter;
+
+static void gbw_raw(GBitWriter *w, const uint8_t *p, size_t n) {
+    if (w->pos + n > w->cap) {
+        w->overflow = 1;
+        return;
+    }
+    memcpy(w->out + w->pos, p, n);
+    w->pos += n;
+}
+
+/* bitwriter.rs:17-31 */
+static void gbw_write_bits(GBitWriter *w, uint64_t bits, uint8_t nbits) {
+    w->buffer |= bits << w->nbits;
+    w->nbits = (uint8_t)(w->nbits + nbits);
+    if (w->nbits >= 64) {
+        uint8_t b[8];
+        for (int i = 0; i < 8; i++) {
+            b[i] = (uint8_t)(w->buffer >> (8 * i));
+        }
+        gbw_raw(w, b, 8);
+        w->nbits = (uint8_t)(w->nbits - 64);
+        unsigned sh = (unsigned)(nbits - w->nbits);
+        w->buffer = sh >= 64 ? 0 : bits >> sh; /* checked_shr(..).unwrap_or(0) */
+    }
+}
+
+/* bitwriter.rs:33-45 */
+static void gbw_flush(GBitWriter *w) {
+    if (w->nbits % 8 != 0) {
+        gbw_write_bits(w, 0, (uint8_t)(8 - w->nbits % 8));
+    }
+    if (w->nbits > 0) {
+        uint8_t b[8];
+        for (int i = 0; i < 8; i++) {
+            b[i] = (uint8_t)(w->buffer >> (8 * i));
+        }
+        gbw_raw(w, b, w->nbits / 8u);
+        w->buffer = 0;
+        w->nbits = 0;
+    }
+}
+
+/* ---- build_huffman_tree (bitstream.rs:198-325) ---- */
+typedef struct {
+    uint32_t f;
+    uint16_t idx;
+} HItem;
+/* Ord for Item: `other.0.cmp(&self.0)` (bitstream.rs:219-223): a <= b  <=>  a.f >= b.f */
+static int hi_le(HItem a, HItem b) { return a.f >= b.f; }
+static int hi_ge(HItem a, HItem b) { return a.f <= b.f; }
+static int hi_lt(HItem a, HItem b) { return a.f > b.f; }
+
+/* std::collections::BinaryHeap::sift_down_range */
+static void heap_sift_down_range(HItem *d, size_t pos, size_t end) {
+    HItem elem = d[pos];
+    size_t hole = pos, child = 2 * hole + 1;
+    size_t lim = end >= 2 ? end - 2 : 0;
+    while (child <= lim) {
+        if (hi_le(d[child], d[child + 1])) {
+            child++;
+        }
+        if (hi_ge(elem, d[child])) {
+            d[hole] = elem;
+            return;
+        }
+        d[hole] = d[child];
+        hole = child;
+        child = 2 * hole + 1;
+    }
+    if (child == end - 1 && hi_lt(elem, d[child])) {
+        d[hole] = d[child];
+        hole = child;
+    }
+    d[hole] = elem;
+}
+/* std::collections::BinaryHeap::pop = swap with the last, sift_down_to_bottom(0), sift_up */
+static HItem heap_pop(HItem *d, size_t *len) {
+    HItem item = d[*len - 1];
+    (*len)--;
+    if (*len > 0) {
+        HItem t = d[0];
+        d[0] = item;
+        item = t;
+        size_t end = *len, hole = 0, child = 1;
+        HItem elem = d[0];
+        size_t lim = end >= 2 ? end - 2 : 0;
+        while (child <= lim) {
+            if (hi_le(d[child], d[child + 1])) {
+                child++;
+            }
+            d[hole] = d[child];
+            hole = child;
+            child = 2 * hole + 1;
+        }
+        if (child == end - 1) {
+            d[hole] = d[child];
+            hole = child;
+        }
+        /* sift_up(0, hole) */
+        while (hole > 0) {
+            size_t parent = (hole - 1) / 2;
+            if (hi_le(elem, d[parent])) {
+                break;
+            }
+            d[hole] = d[parent];
+            hole = parent;
+        }
+        d[hole] = elem;
+    }
+    return item;
+}
+
+static int g_build_huffman_tree(const uint32_t *freq, size_t n, uint8_t *lengths, uint16_t *codes,
+                                uint8_t length_limit) {
+    size_t used = 0, first = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (freq[i] > 0) {
+            if (used == 0) {
+                first = i;
+            }
+            used++;
+        }
+    }
+    memset(lengths, 0, n);
+    memset(codes, 0, 2 * n);
+    if (used <= 1) { /* :206-213 */
+        if (used == 1) {
+            lengths[first] = 1;
+        }
+        return 0;
+    }
+    HItem heap[286];
+    uint16_t in_left[286], in_right[286];
+    size_t hl = 0, ni = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (freq[i] > 0) {
+            heap[hl].f = freq[i];
+            heap[hl].idx = (uint16_t)i;
+            hl++;
+        }
+    }
+    for (size_t k = hl / 2; k > 0;) { /* BinaryHeap::from(vec): rebuild */
+        k--;
+        heap_sift_down_range(heap, k, hl);
+    }
+    while (hl > 1) { /* :236-244 */
+        HItem a = heap_pop(heap, &hl);
+        in_left[ni] = a.idx;
+        in_right[ni] = heap[0].idx;
+        ni++;
+        heap[0].f = a.f + heap[0].f;
+        heap[0].idx = (uint16_t)(ni + n - 1);
+        heap_sift_down_range(heap, 0, hl); /* PeekMut::drop */
+    }
+    /* :247-259 walk the tree */
+    struct {
+        uint16_t node;
+        int depth;
+    } stack[600];
+    size_t sp = 0;
+    stack[sp].node = heap[0].idx;
+    stack[sp].depth = 0;
+    sp++;
+    while (sp > 0) {
+        sp--;
+        uint16_t node = stack[sp].node;
+        int depth = stack[sp].depth;
+        if (node < n) {
+            lengths[node] = (uint8_t)depth;
+        } else {
+            stack[sp].node = in_left[node - n];
+            stack[sp].depth = depth + 1;
+            sp++;
+            stack[sp].node = in_right[node - n];
+            stack[sp].depth = depth + 1;
+            sp++;
+        }
+    }
+    /* :262-305 limit the lengths */
+    uint8_t max_length = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (lengths[i] > max_length) {
+            max_length = lengths[i];
+        }
+    }
+    if (max_length > length_limit) {
+        uint32_t counts[16] = {0};
+        for (size_t i = 0; i < n; i++) {
+            counts[lengths[i] < length_limit ? lengths[i] : length_limit]++;
+        }
+        uint32_t total = 0;
+        for (unsigned i = 1; i <= length_limit; i++) {
+            total += counts[i] << (length_limit - i);
+        }
+        while (total > (1u << length_limit)) {
+            unsigned i = length_limit - 1u;
+            while (counts[i] == 0) {
+                i--;
+            }
+            counts[i]--;
+            counts[length_limit]--;
+            counts[i + 1] += 2;
+            total--;
+        }
+        /* sort_unstable_by_key(frequency): stable order restated (see the section header) */
+        uint16_t order[286];
+        for (size_t i = 0; i < n; i++) {
+            order[i] = (uint16_t)i;
+        }
+        for (size_t i = 1; i < n; i++) {
+            uint16_t v = order[i];
+            size_t j = i;
+            while (j > 0 && freq[order[j - 1]] > freq[v]) {
+                order[j] = order[j - 1];
+                j--;
+            }
+            order[j] = v;
+        }
+        uint8_t len = length_limit;
+        for (size_t k = 0; k < n; k++) {
+            size_t i = order[k];
+            if (freq[i] > 0) {
+                while (counts[len] == 0) {
+                    len--;
+                }
+                lengths[i] = len;
+                counts[len]--;
+            }
+        }
+    }
+    /* :308-320 canonical codes, bit-reversed */
+    uint32_t code = 0;
+    for (unsigned len = 1; len <= length_limit; len++) {
+        for (size_t i = 0; i < n; i++) {
+            if (lengths[i] == len) {
+                uint16_t c = (uint16_t)code, r = 0;
+                for (int b = 0; b < 16; b++) {
+                    r = (uint16_t)((r << 1) | ((c >> b) & 1));
+                }
+                codes[i] = (uint16_t)(r >> (16 - len));
+                code++;
+            }
+        }
+        code <<= 1;
+    }
+    return 1;
+}
+
+/* Symbol (bitstream.rs:29-39): a literal run [start, end) or a back-reference */
+typedef struct {
+    uint32_t a; /* LiteralRun: start          | Backref: length | 0x80000000 */
+    uint32_t b; /* LiteralRun: end            | Backref: distance | dist_sym << 16 */
+} GSymbol;
+#define GSYM_IS_BACKREF(s) (((s).a & 0x80000000u) != 0)
+
+/* distance_to_dist_sym (bitstream.rs:16-27) */
+static uint8_t g_distance_to_dist_sym(uint16_t distance) {
+    static const uint8_t LOOKUP[16] = {0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7};
+    if (distance <= 16) {
+        return LOOKUP[distance - 1];
+    }
+    uint8_t dist_sym = 29;
+    while (dist_sym > 0 && distance < DIST_SYM_TO_DIST_BASE[dist_sym]) {
+        dist_sym--;
+    }
+    return dist_sym;
+}
+
+static const uint32_t G_BITMASKS[17] = {0x0000, 0x0001, 0x0003, 0x0007, 0x000F, 0x001F, 0x003F, 0x007F, 0x00FF,
+                                        0x01FF, 0x03FF, 0x07FF, 0x0FFF, 0x1FFF, 0x3FFF, 0x7FFF, 0xFFFF};
+
+/* write_block (bitstream.rs:41-195) */
+static void g_write_block(GBitWriter *w, const uint8_t *data, uint32_t base_index, const GSymbol *symbols,
+                          size_t nsym, int eof) {
+    uint32_t frequencies[286] = {0}, dist_frequencies[30] = {0};
+    frequencies[256] = 1;
+    for (size_t k = 0; k < nsym; k++) { /* the f2/f3/f4 split of :48-78 only reorders the additions */
+        if (GSYM_IS_BACKREF(symbols[k])) {
+            unsigned length = symbols[k].a & 0xFFFF, dist_sym = symbols[k].b >> 16;
+            frequencies[LENGTH_TO_SYMBOL[length - 3]]++;
+            dist_frequencies[dist_sym]++;
+        } else {
+            for (uint32_t p = symbols[k].a - base_index; p < symbols[k].b - base_index; p++) {
+                frequencies[data[p]]++;
+            }
+        }
+    }
+    uint8_t lengths[286], dist_lengths[30], cl_lengths[19];
+    uint16_t codes[286], dist_codes[30], cl_codes[19];
+    g_build_huffman_tree(frequencies, 286, lengths, codes, 15);
+    g_build_huffman_tree(dist_frequencies, 30, dist_lengths, dist_codes, 15);
+    size_t num_litlen_codes = 286, num_dist_codes = 30;
+    while (num_litlen_codes > 257 && lengths[num_litlen_codes - 1] == 0) {
+        num_litlen_codes--;
+    }
+    while (num_dist_codes > 1 && dist_lengths[num_dist_codes - 1] == 0) {
+        num_dist_codes--;
+    }
+    uint32_t cl_freq[19] = {0};
+    for (size_t i = 0; i < num_litlen_codes; i++) {
+        cl_freq[lengths[i]]++;
+    }
+    for (size_t i = 0; i < num_dist_codes; i++) {
+        cl_freq[dist_lengths[i]]++;
+    }
+    g_build_huffman_tree(cl_freq, 19, cl_lengths, cl_codes, 7);
+
+    gbw_write_bits(w, eof ? 5 : 4, 3); /* 0b101 / 0b100: BFINAL + dynamic */
+    gbw_write_bits(w, num_litlen_codes - 257, 5);
+    gbw_write_bits(w, num_dist_codes - 1, 5);
+    gbw_write_bits(w, 15, 4);
+    for (int j = 0; j < 19; j++) {
+        gbw_write_bits(w, cl_lengths[CLCL_ORDER[j]], 3);
+    }
+    for (size_t i = 0; i < num_litlen_codes; i++) {
+        gbw_write_bits(w, cl_codes[lengths[i]], cl_lengths[lengths[i]]);
+    }
+    for (size_t i = 0; i < num_dist_codes; i++) {
+        gbw_write_bits(w, cl_codes[dist_lengths[i]], cl_lengths[dist_lengths[i]]);
+    }
+    for (size_t k = 0; k < nsym; k++) {
+        if (GSYM_IS_BACKREF(symbols[k])) {
+            unsigned length = symbols[k].a & 0xFFFF, distance = symbols[k].b & 0xFFFF, dist_sym = symbols[k].b >> 16;
+            unsigned sym = LENGTH_TO_SYMBOL[length - 3];
+            gbw_write_bits(w, codes[sym], lengths[sym]);
+            uint8_t len_extra = LENGTH_TO_LEN_EXTRA[length - 3];
+            gbw_write_bits(w, (length - 3) & G_BITMASKS[len_extra], len_extra);
+            gbw_write_bits(w, dist_codes[dist_sym], dist_lengths[dist_sym]);
+            gbw_write_bits(w, distance - DIST_SYM_TO_DIST_BASE[dist_sym], DIST_SYM_TO_DIST_EXTRA[dist_sym]);
+        } else {
+            /* groups of four literals in one write_bits (:134-160): the byte stream does not depend
+             * on how the bits are grouped, but the 64-bit accumulator hand-over does not either */
+            uint32_t p = symbols[k].a - base_index, end = symbols[k].b - base_index;
+            for (; p + 4 <= end; p += 4) {
+                uint8_t l0 = lengths[data[p]], l1 = lengths[data[p + 1]], l2 = lengths[data[p + 2]],
+                        l3 = lengths[data[p + 3]];
+                uint64_t v = (uint64_t)codes[data[p]] | ((uint64_t)codes[data[p + 1]] << l0) |
+                             ((uint64_t)codes[data[p + 2]] << (l0 + l1)) | ((uint64_t)codes[data[p + 3]] << (l0 + l1 + l2));
+                gbw_write_bits(w, v, (uint8_t)(l0 + l1 + l2 + l3));
+            }
+            for (; p < end; p++) {
+                gbw_write_bits(w, codes[data[p]], lengths[data[p]]);
+            }
+        }
+    }
+    gbw_write_bits(w, codes[256], lengths[256]);
+}
+
+/* ---- match finders ---- */
+typedef struct {
+    uint16_t length, distance;
+    size_t start;
+} GMatch;
+static GMatch gm_empty(void) {
+    GMatch m = {0, 0, 0};
+    return m;
+}
+static size_t gm_end(GMatch m) { return m.start + m.length; }
+
+static uint64_t g_load64(const uint8_t *p) {
+    uint64_t v;
+    memcpy(&v, p, 8); /* from_le_bytes / from_ne_bytes: little-endian hosts only (as the oracle's fill_buffer) */
+    return v;
+}
+/* compute_hash (matchfinder/mod.rs:42-44) */
+static uint32_t g_compute_hash(uint64_t v) { return (uint32_t)((11400714785074694791ull * v) >> 40); }
+
+/* match_length::<true> (matchfinder/mod.rs:51-111) */
+static void g_match_length8(uint64_t value, const uint8_t *data, size_t len, size_t anchor, size_t ip, size_t prev_index,
+                            uint16_t *out_len, size_t *out_start) {
+    uint64_t prev = g_load64(data + prev_index);
+    if (value != prev) {
+        *out_len = 0;
+        *out_start = ip;
+        return;
+    }
+    size_t length = 8;
+    while (length < 258 && ip > anchor && prev_index > 0 && data[ip - 1] == data[prev_index - 1]) {
+        length++;
+        ip--;
+        prev_index--;
+    }
+    size_t slice = len - ip - length;
+    if (slice > 258 - length) {
+        slice = 258 - length;
+    }
+    const uint8_t *a = data + ip + length, *b = data + prev_index + length;
+    size_t k = 0;
+    int done = 0;
+    for (; k + 8 <= slice; k += 8) {
+        uint64_t x = g_load64(a + k), y = g_load64(b + k);
+        if (x == y) {
+            length += 8;
+        } else {
+            length += (size_t)__builtin_ctzll(x ^ y) / 8;
+            done = 1;
+            break;
+        }
+    }
+    if (!done) {
+        for (; k < slice; k++) {
+            if (a[k] != b[k]) {
+                break;
+            }
+            length++;
+        }
+    }
+    *out_len = (uint16_t)length;
+    *out_start = ip;
+}
+
+/* rle_match (matchfinder/mod.rs:113-145) */
+static GMatch g_rle_match(const uint8_t *data, size_t len, size_t last_match, size_t ip) {
+    uint8_t value = data[ip];
+    GMatch m = {4, 1, ip + 1};
+    size_t min_start = 1;
+    if (last_match > min_start) {
+        min_start = last_match;
+    }
+    size_t e = gm_end(m);
+    if (e > 258 && e - 258 > min_start) {
+        min_start = e - 258;
+    }
+    while (m.start > min_start && data[m.start - 2] == value) {
+        m.start--;
+        m.length++;
+    }
+    const uint8_t *p = data + gm_end(m);
+    size_t n = len - gm_end(m);
+    if (n > (size_t)(258 - m.length)) {
+        n = (size_t)(258 - m.length);
+    }
+    uint64_t v8 = 0x0101010101010101ull * value;
+    size_t k = 0;
+    for (; k + 8 <= n; k += 8) {
+        uint64_t c = g_load64(p + k);
+        if (c != v8) {
+            m.length = (uint16_t)(m.length + __builtin_ctzll(c ^ v8) / 8);
+            return m;
+        }
+        m.length += 8;
+    }
+    for (; k < n; k++) {
+        if (p[k] != value) {
+            break;
+        }
+        m.length++;
+    }
+    return m;
+}
+
+#define G_MAX_SYMBOLS (16384 + 8)
+typedef struct {
+    int use_hash;         /* 1: HashTableMatchFinder (level 1), 0: NullMatchFinder (RLE) */
+    uint32_t *hash_table; /* CACHE_SIZE = 1 << 16 entries */
+    uint8_t skip_ahead_shift;
+    GSymbol *symbols;
+    size_t nsym;
+    size_t ip, last_match, last_block_end;
+    uint32_t last_index;
+    GMatch m; /* GreedyParser::m */
+} GParser;
+
+/* HashTableMatchFinder::get_and_insert (hashtable.rs:16-50) / NullMatchFinder */
+static GMatch g_get_and_insert(GParser *ps, const uint8_t *data, size_t len, uint32_t base_index, size_t anchor,
+                               size_t ip, uint64_t value) {
+    if (!ps->use_hash) {
+        return gm_empty();
+    }
+    uint32_t sub = (uint32_t)ip > 32768 ? (uint32_t)ip - 32768 : 0;
+    uint32_t min_offset = base_index + sub;
+    if (min_offset < 1) {
+        min_offset = 1;
+    }
+    uint32_t hash_index = g_compute_hash(value) % 65536u;
+    uint32_t offset = ps->hash_table[hash_index];
+    ps->hash_table[hash_index] = (uint32_t)ip + base_index;
+    if (offset >= min_offset) {
+        uint16_t length;
+        size_t start;
+        g_match_length8(value, data, len, anchor, ip, (size_t)(offset - base_index), &length, &start);
+        if (length >= 8) {
+            GMatch m = {length, (uint16_t)(ip - (size_t)(offset - base_index)), start};
+            return m;
+        }
+    }
+    return gm_empty();
+}
+
+/* ParserInner::get_match (parse/mod.rs:58-85) */
+static GMatch g_get_match(GParser *ps, const uint8_t *data, size_t len, uint32_t base_index, int fizzle) {
+    uint64_t current = g_load64(data + ps->ip);
+    if ((uint32_t)current == (uint32_t)(current >> 8)) {
+        GMatch m = g_rle_match(data, len, ps->last_match, ps->ip);
+        ps->ip = gm_end(m) - 3;
+        return m;
+    }
+    size_t anchor = fizzle ? ps->ip : ps->last_match;
+    GMatch m = g_get_and_insert(ps, data, len, base_index, anchor, ps->ip, current);
+    if (fizzle) {
+        while (m.length < 258 && m.start > ps->last_match && m.start > (size_t)m.distance + 1 &&
+               data[m.start - 1] == data[m.start - m.distance - 1]) {
+            m.length++;
+            m.start--;
+        }
+    }
+    ps->ip++;
+    return m;
+}
+
+/* ParserInner::advance_to_match (parse/mod.rs:88-102) */
+static GMatch g_advance_to_match(GParser *ps, const uint8_t *data, size_t len, uint32_t base_index, size_t max_ip) {
+    while (ps->ip < max_ip) {
+        GMatch m = g_get_match(ps, data, len, base_index, 0);
+        if (m.length != 0) {
+            return m;
+        }
+        ps->ip += (ps->ip - ps->last_match) >> ps->skip_ahead_shift;
+    }
+    return gm_empty();
+}
+
+/* ParserInner::advance (parse/mod.rs:105-114) */
+static void g_advance(GParser *ps, const uint8_t *data, size_t len, uint32_t base_index, size_t end) {
+    size_t stop = end < len - 8 ? end : len - 8;
+    if (ps->use_hash) {
+        for (size_t j = ps->ip; j < stop; j++) {
+            ps->hash_table[g_compute_hash(g_load64(data + j)) % 65536u] = base_index + (uint32_t)j;
+        }
+    }
+    if (end > ps->ip) {
+        ps->ip = end;
+    }
+}
+
+/* ParserInner::insert_match (parse/mod.rs:117-131) */
+static void g_insert_match(GParser *ps, uint32_t base_index, GMatch m) {
+    if (m.start > ps->last_match) {
+        ps->symbols[ps->nsym].a = base_index + (uint32_t)ps->last_match;
+        ps->symbols[ps->nsym].b = base_index + (uint32_t)m.start;
+        ps->nsym++;
+    }
+    ps->symbols[ps->nsym].a = 0x80000000u | m.length;
+    ps->symbols[ps->nsym].b = m.distance | ((uint32_t)g_distance_to_dist_sym(m.distance) << 16);
+    ps->nsym++;
+    ps->last_match = gm_end(m);
+}
+
+/* ParserInner::write_block_if_ready (parse/mod.rs:134-150) */
+static void g_write_block_if_ready(GParser *ps, GBitWriter *w, const uint8_t *data, size_t len, uint32_t base_index,
+                                   int finish) {
+    if (ps->nsym >= 16384) {
+        int last_block = finish && ps->last_match == len;
+        g_write_block(w, data, base_index, ps->symbols, ps->nsym, last_block);
+        ps->nsym = 0;
+        ps->last_block_end = ps->last_match;
+    }
+}
+
+/* start_compress (parse/mod.rs:46-55) + end_compress (:152-180).  flush: 0 None, 2 Finish. */
+static size_t g_start_compress(GParser *ps, uint32_t base_index, size_t start) {
+    uint32_t delta = base_index - ps->last_index;
+    ps->ip -= delta;
+    ps->last_match -= delta;
+    ps->last_block_end = start;
+    ps->last_index = base_index;
+    return delta;
+}
+static size_t g_end_compress(GParser *ps, GBitWriter *w, const uint8_t *data, size_t len, uint32_t base_index,
+                             size_t start, int finish) {
+    if (finish && (ps->nsym != 0 || ps->last_match < len)) {
+        if (ps->ip > len) {
+            ps->ip = len;
+        }
+        if (ps->last_match < len) {
+            ps->symbols[ps->nsym].a = base_index + (uint32_t)ps->last_match;
+            ps->symbols[ps->nsym].b = base_index + (uint32_t)len;
+            ps->nsym++;
+            ps->ip = len;
+            ps->last_match = len;
+        }
+        g_write_block(w, data, base_index, ps->symbols, ps->nsym, 1);
+        ps->nsym = 0;
+        ps->last_block_end = ps->ip;
+    }
+    return ps->last_block_end - start;
+}
+
+/* GreedyParser::compress (parse/greedy.rs:27-91) */
+static size_t g_greedy_compress(GParser *ps, GBitWriter *w, const uint8_t *data, size_t len, uint32_t base_index,
+                                size_t start, int finish) {
+    size_t delta = g_start_compress(ps, base_index, start);
+    if (ps->m.length != 0) {
+        ps->m.start -= delta;
+    }
+    size_t lookahead = finish ? 7 : 258 + 8;
+    size_t max_ip = len > lookahead ? len - lookahead : 0;
+    for (;;) {
+        if (ps->m.length == 0) {
+            ps->m = g_advance_to_match(ps, data, len, base_index, max_ip);
+            if (ps->m.length == 0) {
+                break;
+            }
+        }
+        g_advance(ps, data, len, base_index, gm_end(ps->m));
+        GMatch m2 = gm_empty();
+        if (ps->ip < max_ip) {
+            m2 = g_get_match(ps, data, len, base_index, 1);
+        } else if (!finish) {
+            break;
+        }
+        if (m2.length == 0 || m2.start > ps->m.start + 1) {
+            g_insert_match(ps, base_index, ps->m);
+            g_write_block_if_ready(ps, w, data, len, base_index, finish);
+            if (m2.length != 0 && m2.start < ps->last_match) {
+                m2.length = (uint16_t)(m2.length - (ps->last_match - m2.start));
+                m2.start = ps->last_match;
+                if (m2.length < 4) {
+                    m2 = gm_empty();
+                }
+            }
+        }
+        ps->m = m2;
+    }
+    return g_end_compress(ps, w, data, len, base_index, start, finish);
+}
+
+/* RleParser::compress (parse/rle.rs:22-47) */
+static size_t g_rle_compress(GParser *ps, GBitWriter *w, const uint8_t *data, size_t len, uint32_t base_index,
+                             size_t start, int finish) {
+    g_start_compress(ps, base_index, start);
+    size_t lookahead = finish ? 7 : 258;
+    size_t max_ip = len > lookahead ? len - lookahead : 0;
+    for (;;) {
+        GMatch m = g_advance_to_match(ps, data, len, base_index, max_ip);
+        if (m.length == 0) {
+            break;
+        }
+        ps->ip = gm_end(m);
+        g_insert_match(ps, base_index, m);
+        g_write_block_if_ready(ps, w, data, len, base_index, finish);
+    }
+    return g_end_compress(ps, w, data, len, base_index, start, finish);
+}
+
+/* CompressorInner::compress (compress/mod.rs:226-290) for the Fast / Rle variants */
+static size_t g_inner_compress(GParser *ps, GBitWriter *w, const uint8_t *data, size_t len, uint32_t base_index,
+                               size_t start, int finish) {
+    if (finish && len == start) { /* :234-238 */
+        gbw_write_bits(w, 3, 10);
+        gbw_flush(w);
+        return 0;
+    }
+    return ps->use_hash ? g_greedy_compress(ps, w, data, len, base_index, start, finish)
+                        : g_rle_compress(ps, w, data, len, base_index, start, finish);
+}
+
+/* compress_to_vec (level 1, compress/mod.rs:294-303) / compress_to_vec_rle (:306-310):
+ * Compressor::new / new_rle (:69-123), ONE write_data (:126-190, the "no buffered input" branch:
+ * the parser runs over the caller's buffer with Flush::None, then the window tail is kept), then
+ * finish (:194-214) over the kept tail with Flush::Finish.  Returns bytes written, 0 if out_cap is
+ * too small. */
+static size_t g_compress(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap, int rle) {
+    ensure_tables();
+    if (len > (1u << 30)) {
+        return 0; /* write_data splits inputs above 1 GiB into several calls (:130-136): not restated */
+    }
+    GBitWriter w = {0, 0, out, out_cap, 0, 0};
+    const uint8_t hdr[2] = {0x78, 0x01};
+    gbw_raw(&w, hdr, 2);
+    GParser ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.use_hash = !rle;
+    ps.skip_ahead_shift = 5; /* GreedyParser::new(5, ..) :76 / RleParser::new(5) :114 */
+    ps.hash_table = rle ? NULL : (uint32_t *)calloc(65536, sizeof(uint32_t));
+    ps.symbols = (GSymbol *)malloc(sizeof(GSymbol) * G_MAX_SYMBOLS);
+    size_t window_size = rle ? 1 : 32768;
+    uint32_t adler = fdo_adler32(input, len);
+    /* write_data */
+    size_t written = g_inner_compress(&ps, &w, input, len, 0, 0, 0);
+    size_t start = written > window_size ? written - window_size : 0;
+    const uint8_t *kept = input + start; /* input.data = data[start..] */
+    size_t kept_len = len - start;
+    uint32_t base_index = (uint32_t)start;
+    size_t input_written = written - start;
+    /* finish */
+    g_inner_compress(&ps, &w, kept, kept_len, base_index, input_written, 1);
+    gbw_flush(&w);
+    const uint8_t tr[4] = {(uint8_t)(adler >> 24), (uint8_t)(adler >> 16), (uint8_t)(adler >> 8), (uint8_t)adler};
+    gbw_raw(&w, tr, 4);
+    free(ps.hash_table);
+    free(ps.symbols);
+    return w.overflow ? 0 : w.pos;
+}
+
+size_t fdo_compress_bound(size_t len) { return len + len / 2 + 1024; }
+size_t fdo_compress_level1(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap) {
+    return g_compress(input, len, out, out_cap, 0);
+}
+size_t fdo_compress_rle(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap) {
+    return g_compress(input, len, out, out_cap, 1);
+}

@@ -112,6 +112,13 @@ size_t fdo_compress_ultra_fast(const uint8_t *input, size_t len, uint8_t *out, s
  * 194-214, 234-268); used only to generate stored-block test streams. */
 size_t fdo_compress_stored(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap);
 
+/* ---- general encoder, level 1 and RLE (src/compress/mod.rs:294-310; parse/, matchfinder/,
+ * bitstream.rs): compress_to_vec / compress_to_vec_rle.  Return bytes written, 0 if out_cap is too
+ * small (fdo_compress_bound(len) always suffices).  Parity pin: see the section header in the .c. */
+size_t fdo_compress_bound(size_t len);
+size_t fdo_compress_level1(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap);
+size_t fdo_compress_rle(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap);
+
 /* ---- batch helpers for the CPU baseline leg (one stream per task, pthreads) ---- */
 void fdo_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
                        const uint64_t *out_off, uint32_t *out_len, uint32_t *status,

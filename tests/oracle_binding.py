@@ -73,6 +73,11 @@ def lib():
         L.fdo_compress_ultra_fast.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.fdo_compress_stored.restype = C.c_size_t
         L.fdo_compress_stored.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        for name in ("fdo_compress_level1", "fdo_compress_rle"):
+            getattr(L, name).restype = C.c_size_t
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.fdo_compress_bound.restype = C.c_size_t
+        L.fdo_compress_bound.argtypes = [C.c_size_t]
         L.fdo_inflate_batch.restype = None
         L.fdo_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
@@ -121,6 +126,25 @@ def compress_ultra_fast(data):
     out = np.zeros(cap, dtype=np.uint8)
     n = lib().fdo_compress_ultra_fast(p, a.size, out.ctypes.data_as(C.c_void_p), cap)
     return out[:n].tobytes()
+
+
+def _compress_general(fn, data):
+    a, p = _buf(data)
+    cap = lib().fdo_compress_bound(a.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = fn(p if a.size else None, a.size, out.ctypes.data_as(C.c_void_p), cap)
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def compress_level1(data):
+    """compress_to_vec (level 1, src/compress/mod.rs:294)"""
+    return _compress_general(lib().fdo_compress_level1, data)
+
+
+def compress_rle(data):
+    """compress_to_vec_rle (src/compress/mod.rs:306)"""
+    return _compress_general(lib().fdo_compress_rle, data)
 
 
 def compress_stored(data):

@@ -601,3 +601,35 @@ def test_mixed_batch_on_every_visible_device(harness):
         b = torch.zeros(2, dtype=torch.int64, device="cuda:1")
         with pytest.raises(ValueError):
             fd.inflate_batch(a, b, a, b)
+
+
+def test_general_encoder_level1_and_rle_bit_exact(harness):
+    """compress_to_vec (level 1) and compress_to_vec_rle on the GPU (one stream per lane) against the
+    oracle's restatement: bit-exact, batch and host conveniences, guard bytes behind every slot."""
+    import torch
+    import fdeflate_amd as fd
+    from test_oracle_golden import _encoder_inputs
+    raws = _encoder_inputs()
+    r = np.random.default_rng(17)
+    for k in range(70):   # more than one wavefront of streams, ragged sizes
+        n = int(r.integers(0, 9000))
+        raws.append(bytes(r.integers(0, int(r.integers(2, 256)), n, dtype=np.uint8)))
+    assert fd.compress_to_vec(b"") == bytes.fromhex("7801030000000001")
+    assert fd.compress_to_vec(b"Hello world!") == ob.compress_level1(b"Hello world!")
+    assert fd.compress_to_vec_rle(bytes(3000)) == ob.compress_rle(bytes(3000))
+    buf, in_off = streams.pack_exact(raws)
+    caps = [fd.compress_bound(len(x)) + 5 for x in raws]
+    out_off = np.zeros(len(raws) + 1, dtype=np.int64)
+    out_off[1:] = np.cumsum(caps)
+    d_in = torch.from_numpy(buf).cuda()
+    d_in_off = torch.from_numpy(in_off.astype(np.int64)).cuda()
+    d_out_off = torch.from_numpy(out_off).cuda()
+    for mode, enc in ((fd.MODE_LEVEL1, ob.compress_level1), (fd.MODE_RLE, ob.compress_rle)):
+        d_out = torch.full((int(out_off[-1]),), 0x5A, dtype=torch.uint8, device="cuda")
+        ln = fd.deflate_general_batch(d_in, d_in_off, d_out, d_out_off, mode).cpu().numpy().view(np.uint32)
+        h = d_out.cpu().numpy()
+        for i, raw in enumerate(raws):
+            exp = enc(raw)
+            got = h[out_off[i]:out_off[i] + int(ln[i])].tobytes()
+            assert got == exp, (mode, i, len(raw), int(ln[i]), len(exp))
+            assert np.all(h[out_off[i] + int(ln[i]):out_off[i + 1]] == 0x5A), (mode, i)
