@@ -9,12 +9,13 @@ from .api import (Decompressor, DecompressionError, OutputTooLarge, STATUS_NAMES
                   decompress_to_vec, decompress_to_vec_bounded, deflate_ultrafast_batch,
                   inflate_batch, ultrafast_bound, compress_to_vec_stored, deflate_stored_batch,
                   stored_size, compress_to_vec, compress_to_vec_rle, compress_bound, deflate_general_batch,
-                  MODE_LEVEL1, MODE_RLE)
+                  MODE_LEVEL1, MODE_RLE, inflate_batch_multi, init_devices, shutdown_devices)
 
 __all__ = [
     "Decompressor", "DecompressionError", "OutputTooLarge", "STATUS_NAMES", "FLAG_IGNORE_ADLER32",
     "FLAG_SERIAL_ONLY", "FLAG_GENERAL_ONLY", "FLAG_NO_RECHECK", "compress_to_vec_ultra_fast", "debug_build_tables", "decompress_to_vec",
     "decompress_to_vec_bounded", "deflate_ultrafast_batch", "inflate_batch", "ultrafast_bound",
     "compress_to_vec_stored", "deflate_stored_batch", "stored_size", "compress_to_vec", "compress_to_vec_rle",
-    "compress_bound", "deflate_general_batch", "MODE_LEVEL1", "MODE_RLE",
+    "compress_bound", "deflate_general_batch", "MODE_LEVEL1", "MODE_RLE", "inflate_batch_multi", "init_devices",
+    "shutdown_devices",
 ]

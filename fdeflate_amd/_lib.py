@@ -56,6 +56,12 @@ def lib():
     L.fdh_compress_to_vec_ultra_fast.restype = C.c_int
     L.fdh_compress_to_vec_ultra_fast.argtypes = [vp, sz, pp, C.POINTER(sz)]
     L.fdh_free.argtypes = [vp]
+    L.fdh_init.restype = C.c_int
+    L.fdh_init.argtypes = [u64]
+    L.fdh_shutdown.restype = C.c_int
+    L.fdh_multi_device_count.restype = C.c_int
+    L.fdh_inflate_batch_multi.restype = C.c_int
+    L.fdh_inflate_batch_multi.argtypes = [vp, u32, u32, u64]
     L.fdh_compress_bound.restype = u64
     L.fdh_compress_bound.argtypes = [u64]
     L.fdh_deflate_general_batch.restype = C.c_int
@@ -86,7 +92,15 @@ EXPORTED_SYMBOLS = [
     "fdh_decompressor_new", "fdh_decompressor_free", "fdh_decompressor_ignore_adler32",
     "fdh_decompressor_is_done", "fdh_decompressor_read",
     "fdh_compress_bound", "fdh_deflate_general_batch", "fdh_compress_to_vec", "fdh_compress_to_vec_rle",
+    "fdh_init", "fdh_shutdown", "fdh_multi_device_count", "fdh_inflate_batch_multi",
 ]
+
+
+class Shard(C.Structure):
+    """fdh_shard_t"""
+    _fields_ = [("in_", C.c_void_p), ("in_off", C.c_void_p), ("out", C.c_void_p), ("out_off", C.c_void_p),
+                ("out_len", C.c_void_p), ("status", C.c_void_p), ("adler", C.c_void_p), ("n", C.c_uint64),
+                ("meta_all", C.c_void_p)]
 
 
 def check(rc):

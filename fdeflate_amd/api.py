@@ -285,6 +285,44 @@ def deflate_stored_batch(raw, in_off, out, out_off, out_len=None):
     return out_len
 
 
+def inflate_batch_multi(shards, flags=0, gather=True):
+    """fdh_inflate_batch_multi from one process: `shards` = one tuple (comp, in_off, out, out_off) of
+    tensors per GPU selected by init_devices(); returns per shard (out_len, status, adler) and, with
+    gather, the all-gathered results [n_shards, 3, stride] on every device."""
+    import torch
+    L = _lib.lib()
+    n_sh = len(shards)
+    arr = (_lib.Shard * n_sh)()
+    keep, results, metas = [], [], []
+    stride = max(s[1].numel() - 1 for s in shards)
+    for i, (comp, in_off, out, out_off) in enumerate(shards):
+        dev = comp.device
+        n = in_off.numel() - 1
+        ol = torch.empty(n, dtype=torch.int32, device=dev)
+        st = torch.empty(n, dtype=torch.int32, device=dev)
+        ad = torch.empty(n, dtype=torch.int32, device=dev)
+        meta = torch.empty((n_sh, 3, stride), dtype=torch.int32, device=dev) if gather else None
+        keep.append((comp, in_off, out, out_off))
+        results.append((ol, st, ad))
+        metas.append(meta)
+        arr[i] = _lib.Shard(comp.data_ptr(), in_off.data_ptr(), out.data_ptr(), out_off.data_ptr(), ol.data_ptr(),
+                            st.data_ptr(), ad.data_ptr(), n, meta.data_ptr() if gather else None)
+    for t in keep:
+        torch.cuda.synchronize(t[0].device)   # the call runs on the library's own streams
+    _lib.check(L.fdh_inflate_batch_multi(C.byref(arr), n_sh, flags, stride))
+    return results, metas
+
+
+def init_devices(mask=0):
+    """fdh_init: select the GPUs (bit mask, 0 = all visible) for inflate_batch_multi."""
+    _lib.check(_lib.lib().fdh_init(mask))
+    return _lib.lib().fdh_multi_device_count()
+
+
+def shutdown_devices():
+    _lib.check(_lib.lib().fdh_shutdown())
+
+
 def debug_build_tables(code_lengths, hlit):
     """Device Huffman-table builder on one set of 320 code lengths -> (status, litlen, dist, eof)."""
     import torch

@@ -194,6 +194,38 @@ int fdh_compress_to_vec_rle(const uint8_t *input, size_t input_len, uint8_t **ou
                             size_t *output_len); /* compress_to_vec_rle, compress/mod.rs:306 */
 void fdh_free(void *p);
 
+/* ---- several GPUs of one node, one process --------------------------------
+ * Streams are independent: a batch is sharded by contiguous stream ranges, one shard per device,
+ * decoded with no data-path exchange; the only collective is an all-gather of the per-stream
+ * results {status, out_len, adler} over RCCL / xGMI (librccl is loaded on demand, and only when
+ * more than one device takes part).  There is no reference counterpart: the crate is
+ * single-threaded; this is how a batch API scales it across the node.
+ *   fdh_init(device_mask)   devices with bit d set (0 = every visible device): HIP streams, the
+ *                           shared decode tables and the RCCL communicator; call again to change
+ *   fdh_shutdown()          releases them
+ *   fdh_inflate_batch_multi `n_shards` must equal the number of initialised devices; shard i holds
+ *                           device pointers ON device i (the i-th selected one) with the meaning of
+ *                           fdh_inflate_batch.  If `meta_all` is given (for every shard), device i
+ *                           receives the results of ALL shards there: n_shards x 3 x meta_stride
+ *                           words, [shard][status | out_len | adler][stream], zero padded.
+ *                           Returns when every device has finished. */
+typedef struct fdh_shard {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    uint8_t *out;
+    const uint64_t *out_off;
+    uint32_t *out_len;
+    uint32_t *status;
+    uint32_t *adler;    /* nullable */
+    uint64_t n;
+    uint32_t *meta_all; /* nullable (for every shard or for none) */
+} fdh_shard_t;
+int fdh_init(uint64_t device_mask);
+int fdh_shutdown(void);
+int fdh_multi_device_count(void); /* devices selected by the last fdh_init, 0 before */
+int fdh_inflate_batch_multi(const fdh_shard_t *shards, uint32_t n_shards, uint32_t flags,
+                            uint64_t meta_stride);
+
 /* ---- introspection ------------------------------------------------------------------- */
 uint32_t fdh_version(void);
 const char *fdh_status_name(uint32_t stream_status); /* "Ok", "BadZlibHeader", ... */

@@ -1,0 +1,77 @@
+//! `extern "C"` declarations of include/fdeflate_hip.h -- one item per C entry point, each naming
+//! the reference item it stands in for.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const FDH_SUCCESS: c_int = 0;
+pub const FDH_FLAG_IGNORE_ADLER32: u32 = 0x1;
+pub const FDH_OUTPUT_TOO_LARGE: u32 = 17;
+pub const FDH_MODE_LEVEL1: u32 = 1;
+pub const FDH_MODE_RLE: u32 = 2;
+
+#[repr(C)]
+pub struct fdh_decompressor {
+    _private: [u8; 0],
+}
+
+/// `fdh_shard_t`: the device-resident shard of one GPU for `fdh_inflate_batch_multi`.
+#[repr(C)]
+pub struct fdh_shard_t {
+    pub input: *const u8,
+    pub in_off: *const u64,
+    pub out: *mut u8,
+    pub out_off: *const u64,
+    pub out_len: *mut u32,
+    pub status: *mut u32,
+    pub adler: *mut u32,
+    pub n: u64,
+    pub meta_all: *mut u32,
+}
+
+extern "C" {
+    // decompress_to_vec_bounded per stream (src/decompress.rs:1111-1144), device pointers
+    pub fn fdh_inflate_batch(input: *const u8, in_off: *const u64, out: *mut u8, out_off: *const u64,
+                             out_len: *mut u32, status: *mut u32, adler: *mut u32, n: u64, flags: u32,
+                             hip_stream: *mut c_void) -> c_int;
+    // compress_to_vec_ultra_fast per buffer (src/compress/mod.rs:313-317)
+    pub fn fdh_deflate_ultrafast_batch(input: *const u8, in_off: *const u64, out: *mut u8, out_off: *const u64,
+                                       out_len: *mut u32, n: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn fdh_ultrafast_bound(len: u64) -> u64;
+    // compress_to_vec_with_level(.., 0) per buffer (src/compress/mod.rs:299-303)
+    pub fn fdh_deflate_stored_batch(input: *const u8, in_off: *const u64, out: *mut u8, out_off: *const u64,
+                                    out_len: *mut u32, n: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn fdh_stored_size(len: u64) -> u64;
+    // compress_to_vec (level 1) / compress_to_vec_rle per buffer (src/compress/mod.rs:294-310)
+    pub fn fdh_deflate_general_batch(input: *const u8, in_off: *const u64, out: *mut u8, out_off: *const u64,
+                                     out_len: *mut u32, n: u64, mode: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn fdh_compress_bound(len: u64) -> u64;
+
+    // Decompressor (src/decompress.rs:96-156, 179-342)
+    pub fn fdh_decompressor_new() -> *mut fdh_decompressor;
+    pub fn fdh_decompressor_free(d: *mut fdh_decompressor);
+    pub fn fdh_decompressor_ignore_adler32(d: *mut fdh_decompressor);
+    pub fn fdh_decompressor_is_done(d: *const fdh_decompressor) -> c_int;
+    pub fn fdh_decompressor_read(d: *mut fdh_decompressor, input: *const u8, input_len: usize, output: *mut u8,
+                                 output_len: usize, output_position: usize, consumed: *mut usize,
+                                 produced: *mut usize, stream_status: *mut u32) -> c_int;
+
+    // host-memory conveniences (src/lib.rs:29-36 names)
+    pub fn fdh_decompress_to_vec(input: *const u8, len: usize, out: *mut *mut u8, out_len: *mut usize,
+                                 status: *mut u32) -> c_int;
+    pub fn fdh_decompress_to_vec_bounded(input: *const u8, len: usize, maxlen: usize, out: *mut *mut u8,
+                                         out_len: *mut usize, status: *mut u32) -> c_int;
+    pub fn fdh_compress_to_vec_ultra_fast(input: *const u8, len: usize, out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    pub fn fdh_compress_to_vec_stored(input: *const u8, len: usize, out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    pub fn fdh_compress_to_vec(input: *const u8, len: usize, out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    pub fn fdh_compress_to_vec_rle(input: *const u8, len: usize, out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    pub fn fdh_free(p: *mut c_void);
+
+    // several GPUs of a node from one process
+    pub fn fdh_init(device_mask: u64) -> c_int;
+    pub fn fdh_shutdown() -> c_int;
+    pub fn fdh_multi_device_count() -> c_int;
+    pub fn fdh_inflate_batch_multi(shards: *const fdh_shard_t, n_shards: u32, flags: u32, meta_stride: u64) -> c_int;
+
+    pub fn fdh_last_error() -> *const c_char;
+    pub fn fdh_device_count() -> c_int;
+}

@@ -633,3 +633,49 @@ def test_general_encoder_level1_and_rle_bit_exact(harness):
             got = h[out_off[i]:out_off[i] + int(ln[i])].tobytes()
             assert got == exp, (mode, i, len(raw), int(ln[i]), len(exp))
             assert np.all(h[out_off[i] + int(ln[i]):out_off[i + 1]] == 0x5A), (mode, i)
+
+
+def test_multi_gpu_entry_points_every_visible_device(harness):
+    """fdh_init / fdh_inflate_batch_multi / fdh_shutdown: the mixed batch sharded by contiguous
+    ranges over every visible GPU from ONE process, results all-gathered (RCCL when more than one
+    device takes part), compared stream by stream with the oracle."""
+    import torch
+    import fdeflate_amd as fd
+    pool = []
+    for name, comp, raw in streams.valid_streams():
+        pool.append((comp, len(raw)))
+    for name, comp in streams.corpus_streams():
+        pool.append((comp, 1 << 16))
+    for item in streams.error_streams():
+        pool.append((item[1], 4096))
+    g = fd.init_devices(0)
+    try:
+        assert g == torch.cuda.device_count() >= 1
+        per = (len(pool) + g - 1) // g
+        shards, expect = [], []
+        for k in range(g):
+            part = pool[k * per:(k + 1) * per]
+            blobs = [p[0] for p in part]
+            caps = [p[1] for p in part]
+            buf, in_off = streams.pack_exact(blobs)
+            out_off = np.zeros(len(blobs) + 1, dtype=np.int64)
+            out_off[1:] = np.cumsum(np.asarray(caps, dtype=np.int64))
+            dev = torch.device("cuda", k)
+            shards.append((torch.from_numpy(buf).to(dev), torch.from_numpy(in_off.astype(np.int64)).to(dev),
+                           torch.zeros(max(int(out_off[-1]), 1), dtype=torch.uint8, device=dev), torch.from_numpy(out_off).to(dev)))
+            expect.append((harness.oracle_inflate(blobs, caps), out_off))
+        results, metas = fd.inflate_batch_multi(shards)
+        for k in range(g):
+            (rs, rl, ra, ro), out_off = expect[k]
+            ol, st, ad = (t.cpu().numpy().view(np.uint32) for t in results[k])
+            h = shards[k][2].cpu().numpy()
+            for i in range(len(rs)):
+                assert int(st[i]) == rs[i], (k, i)
+                if rs[i] in (0, 17):
+                    assert int(ol[i]) == rl[i] and h[out_off[i]:out_off[i] + rl[i]].tobytes() == ro[i]
+            # every device holds every shard's results
+            for j in range(g):
+                m = metas[j].cpu().numpy().view(np.uint32)
+                assert np.array_equal(m[k, 0, :len(rs)], st) and np.array_equal(m[k, 1, :len(rs)], ol)
+    finally:
+        fd.shutdown_devices()
