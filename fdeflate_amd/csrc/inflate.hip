@@ -284,11 +284,24 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
         // persistent wavefronts: every wavefront keeps fetching the next stream, so a short stream
         // does not leave its slot of the workgroup idle and the table is staged once per workgroup
         const int lane = threadIdx.x & (kWave - 1);
-        for (uint64_t it = 0; it <= a.n; it++) {  // (bounded: a wavefront can never be handed more than n streams)
+        for (;;) {
+            // The hand-out must not depend on WHICH lanes are active: the compiler gives this loop a
+            // per-lane exit mask (it does not know that `next` is uniform), and "lane 0 fetches,
+            // readfirstlane broadcasts" silently breaks once lane 0 is not the first active lane --
+            // readfirstlane then returns another lane's initialiser and the wavefront decodes that
+            // stream for ever (the round-1 "for (;;) hangs" -- reproduced and traced in round 2).  So the
+            // first ACTIVE lane fetches, which is also the lane readfirstlane reads.
             uint32_t next = 0;
-            if (lane == 0) next = atomicAdd(&a.list[1], 1u);
+            const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;
+            if (lane == leader) next = atomicAdd(&a.list[1], 1u);
             next = uni(next);
             if (next >= a.n) break;
+#ifdef FDH_DEBUG_TILES
+            // diagnostics of the stream hand-out: how often was each stream handed out, and was every
+            // lane of the wavefront active here?
+            if (lane == 0 && next < 65536) atomicAdd(&g_handed[next], 1u);
+            if (__ballot(true) != ~0ull) atomicAdd(&g_handed[65536], 1u);
+#endif
             segments_decode(a, lds, next);
         }
     } else {
@@ -366,6 +379,15 @@ __global__ __launch_bounds__(kWave) void build_tables_debug_kernel(const uint8_t
 }  // namespace fdh
 
 #ifdef FDH_DEBUG_TILES
+extern "C" int fdh_debug_read_handed(uint32_t* host, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_handed), 65537 * 4);
+    if (reset) {
+        static uint32_t z[65537];
+        hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_handed), z, sizeof(z));
+    }
+    return 0;
+}
 extern "C" int fdh_debug_read_seg(uint32_t* host) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_segdbg), 64 * 16 * 4);

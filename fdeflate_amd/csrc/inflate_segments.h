@@ -42,6 +42,7 @@ namespace fdh {
 #ifdef FDH_DEBUG_TILES
 __device__ uint32_t g_segdbg[64 * 16];
 __device__ uint32_t g_segdbg2[16 * 16];
+__device__ uint32_t g_handed[65537];  // [i] = times stream i was handed out, [65536] = hand-outs with a partial EXEC
 #define SEGDBG(slot, val) do { if (sid < 64 && lane == 0) g_segdbg[sid * 16 + (slot)] = (val); } while (0)
 #define SEGDBG_ADD(slot, val) do { if (sid < 64 && lane == 0) g_segdbg[sid * 16 + (slot)] += (val); } while (0)
 __device__ uint32_t g_segtime[4096 * 8];

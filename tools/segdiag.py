@@ -61,6 +61,15 @@ print("segment kernel alone: %.3f ms, finished %d of %d streams itself; whole pi
       % (t_first, n - pending, n, t_all, ok, bool(torch.equal(out, raw.view(-1)))))
 print("=> scaled to 65536 streams: %.2f ms" % (t_all * 65536 / n))
 Lc = _lib.lib()
+if hasattr(Lc, "fdh_debug_read_handed"):
+    hb = np.zeros(65537, dtype=np.uint32)
+    Lc.fdh_debug_read_handed(hb.ctypes.data_as(C.c_void_p), 1)
+    fd.inflate_batch(comp, t_off, out, r_off, ol, st, ad, flags=64)
+    torch.cuda.synchronize()
+    Lc.fdh_debug_read_handed(hb.ctypes.data_as(C.c_void_p), 1)
+    k = min(n, 65536)
+    print("stream hand-out: min %d max %d times per stream (first %d streams), hand-outs under a partial EXEC: %d"
+          % (hb[:k].min(), hb[:k].max(), k, hb[65536]))
 if hasattr(Lc, "fdh_debug_read_segtime"):
     fd.inflate_batch(comp, t_off, out, r_off, ol, st, ad, flags=64)
     torch.cuda.synchronize()
