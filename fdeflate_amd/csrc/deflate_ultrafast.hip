@@ -89,6 +89,27 @@ struct Encoder {
         if ((uint32_t)(v >> 32)) atomicOr(&ring[(d + 1) & (kEncRingDw - 1)], (uint32_t)(v >> 32));
     }
 
+    // ORs a value of up to 118 bits {v1:v0} into the ring at bit `pos`: the value is shifted into
+    // place in registers (five dwords) and only the dwords that hold bits touch the LDS -- a chunk of
+    // typical data is one or two atomics instead of one or two per 2-byte piece.
+    __device__ void or_bits128(uint64_t pos, uint64_t v0, uint64_t v1) {
+        const uint32_t s = (uint32_t)pos & 31;
+        const uint32_t d = (uint32_t)(pos >> 5);
+        const uint32_t w0 = (uint32_t)v0, w1 = (uint32_t)(v0 >> 32), w2 = (uint32_t)v1, w3 = (uint32_t)(v1 >> 32);
+        // out[k] = (w[k] << s) | (w[k-1] >> (32 - s)); v_alignbit takes the shift modulo 32, so s = 0 is selected apart
+        const uint32_t r = 32 - s;
+        const uint32_t o0 = w0 << s;
+        const uint32_t o1 = s ? __builtin_amdgcn_alignbit(w1, w0, r) : w1;
+        const uint32_t o2 = s ? __builtin_amdgcn_alignbit(w2, w1, r) : w2;
+        const uint32_t o3 = s ? __builtin_amdgcn_alignbit(w3, w2, r) : w3;
+        const uint32_t o4 = s ? (w3 >> r) : 0u;
+        if (o0) atomicOr(&ring[d & (kEncRingDw - 1)], o0);
+        if (o1) atomicOr(&ring[(d + 1) & (kEncRingDw - 1)], o1);
+        if (o2) atomicOr(&ring[(d + 2) & (kEncRingDw - 1)], o2);
+        if (o3) atomicOr(&ring[(d + 3) & (kEncRingDw - 1)], o3);
+        if (o4) atomicOr(&ring[(d + 4) & (kEncRingDw - 1)], o4);
+    }
+
     // Store every complete 16-B line (all lines when final) and re-zero it in the ring.
     __device__ void flush(bool final) {
         wave_sync();
@@ -180,14 +201,18 @@ struct DeflateBatchArgs {
     uint64_t n;
 };
 
+// Exclusive prefix sum over the wavefront with DPP moves only (row shifts inside each row of 16
+// lanes, then the row broadcasts): no LDS traffic, unlike ds_bpermute-based shuffles.  All lanes active.
 __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t& total) {
     uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        uint32_t y = __shfl_up(x, o, kWave);
-        if (lane >= o) x += y;
-    }
-    total = __shfl(x, kWave - 1, kWave);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, kWave - 1);
+    (void)lane;
     return x - v;
 }
 
@@ -232,11 +257,16 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
 
     const uint64_t nchunks = len / 8;
     uint32_t carry = 0;  // pending run (zero bytes) entering the tile; may exceed 2^32? len < 2^32 assumed below
+    // the chunk of the NEXT tile is requested while this one is encoded (the loads are the only
+    // global-memory latency of the loop)
+    uint64_t x_next = 0;
+    if ((uint64_t)lane < nchunks) x_next = *reinterpret_cast<const uint64_t*>(in + (uint64_t)lane * 8);  // HW handles misalignment
     for (uint64_t t0 = 0; t0 < nchunks; t0 += kWave) {
         const uint64_t c = t0 + lane;
         const bool valid = c < nchunks;
-        uint64_t x = 0;
-        if (valid) x = *reinterpret_cast<const uint64_t*>(in + c * 8);  // HW handles misalignment
+        const uint64_t x = x_next;
+        x_next = 0;
+        if (c + kWave < nchunks) x_next = *reinterpret_cast<const uint64_t*>(in + (c + kWave) * 8);
         const uint32_t nvalid = (uint32_t)min((uint64_t)kWave, nchunks - t0);
         {   // adler partials: weight of byte j of this chunk is len - (c*8 + j)
             uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
@@ -298,6 +328,8 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
             }
         } else {
             uint64_t pos = enc.qbits + off;
+            // the run's leading literal 0 (two zero bits) and its full-length repeats (rare) ...
+            uint32_t pre_bits = 0, pre_n = 0;
             if (pend) {
                 pos += 2;
                 uint32_t rep_bits = e285 & 0xFFFF;
@@ -306,14 +338,18 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
                     enc.or_bits(pos, rep_bits);
                     pos += rep_n;
                 }
-                enc.or_bits(pos, tail_bits);
-                pos += tail_n;
+                pre_bits = tail_bits;  // ... then the tail of the run in front of the chunk's literals
+                pre_n = tail_n;
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                enc.or_bits(pos, pb[k]);
-                pos += pn[k];
-            }
+            // ... and the chunk's literals, packed in registers: <= 22 + 96 bits
+            const uint64_t la = (uint64_t)pb[0] | ((uint64_t)pb[1] << pn[0]);
+            const uint64_t lb = (uint64_t)pb[2] | ((uint64_t)pb[3] << pn[2]);
+            const uint32_t na = pn[0] + pn[1];  // <= 48
+            const uint64_t l0 = la | (lb << na);
+            const uint64_t l1 = na ? lb >> (64 - na) : 0;
+            const uint64_t v0 = (uint64_t)pre_bits | (l0 << pre_n);
+            const uint64_t v1 = (l1 << pre_n) | (pre_n ? l0 >> (64 - pre_n) : 0);
+            enc.or_bits128(pos, v0, v1);
             enc.qbits += total;
         }
         // ---- carry: pending run after this tile ----
