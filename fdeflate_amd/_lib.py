@@ -56,6 +56,12 @@ def lib():
     L.fdh_compress_to_vec_ultra_fast.restype = C.c_int
     L.fdh_compress_to_vec_ultra_fast.argtypes = [vp, sz, pp, C.POINTER(sz)]
     L.fdh_free.argtypes = [vp]
+    L.fdh_png_unfilter_batch.restype = C.c_int
+    L.fdh_png_unfilter_batch.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, vp]
+    L.fdh_png_filter_batch.restype = C.c_int
+    L.fdh_png_filter_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, u32, u32, vp]
+    L.fdh_inflate_png_batch.restype = C.c_int
+    L.fdh_inflate_png_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u32, u32, u32, vp]
     L.fdh_init.restype = C.c_int
     L.fdh_init.argtypes = [u64]
     L.fdh_shutdown.restype = C.c_int
@@ -92,6 +98,7 @@ EXPORTED_SYMBOLS = [
     "fdh_decompressor_new", "fdh_decompressor_free", "fdh_decompressor_ignore_adler32",
     "fdh_decompressor_is_done", "fdh_decompressor_read",
     "fdh_compress_bound", "fdh_deflate_general_batch", "fdh_compress_to_vec", "fdh_compress_to_vec_rle",
+    "fdh_png_unfilter_batch", "fdh_png_filter_batch", "fdh_inflate_png_batch",
     "fdh_init", "fdh_shutdown", "fdh_multi_device_count", "fdh_inflate_batch_multi",
 ]
 

@@ -285,6 +285,48 @@ def deflate_stored_batch(raw, in_off, out, out_off, out_len=None):
     return out_len
 
 
+def png_unfilter_batch(filt, filt_off, pix, pix_off, row_bytes, bpp, png_status=None):
+    """PNG scanline reconstruction of n images, one per lane (fdh_png_unfilter_batch)."""
+    import torch
+    n = filt_off.numel() - 1
+    if png_status is None:
+        png_status = torch.empty(n, dtype=torch.int32, device=filt.device)
+    with _OnDevice(filt, filt_off, pix, pix_off, png_status) as stream:
+        _lib.check(_lib.lib().fdh_png_unfilter_batch(_ptr(filt), _ptr(filt_off), _ptr(pix), _ptr(pix_off),
+                                                    _ptr(png_status), n, row_bytes, bpp, C.c_void_p(stream)))
+    return png_status
+
+
+def png_filter_batch(pix, pix_off, types, types_off, filt, filt_off, row_bytes, bpp, png_status=None):
+    """PNG scanline filtering with the given per-row filter types (fdh_png_filter_batch)."""
+    import torch
+    n = pix_off.numel() - 1
+    if png_status is None:
+        png_status = torch.empty(n, dtype=torch.int32, device=pix.device)
+    with _OnDevice(pix, pix_off, types, types_off, filt, filt_off, png_status) as stream:
+        _lib.check(_lib.lib().fdh_png_filter_batch(_ptr(pix), _ptr(pix_off), _ptr(types), _ptr(types_off), _ptr(filt),
+                                                  _ptr(filt_off), _ptr(png_status), n, row_bytes, bpp,
+                                                  C.c_void_p(stream)))
+    return png_status
+
+
+def inflate_png_batch(comp, in_off, filt, filt_off, pix, pix_off, row_bytes, bpp, flags=0):
+    """Decode n IDAT-style zlib streams and reconstruct their scanlines in one call
+    (fdh_inflate_png_batch) -> (out_len, status, adler, png_status)."""
+    import torch
+    n = in_off.numel() - 1
+    dev = comp.device
+    out_len = torch.empty(n, dtype=torch.int32, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    adler = torch.empty(n, dtype=torch.int32, device=dev)
+    png_status = torch.empty(n, dtype=torch.int32, device=dev)
+    with _OnDevice(comp, in_off, filt, filt_off, pix, pix_off) as stream:
+        _lib.check(_lib.lib().fdh_inflate_png_batch(_ptr(comp), _ptr(in_off), _ptr(filt), _ptr(filt_off), _ptr(out_len),
+                                                   _ptr(status), _ptr(adler), _ptr(pix), _ptr(pix_off),
+                                                   _ptr(png_status), n, flags, row_bytes, bpp, C.c_void_p(stream)))
+    return out_len, status, adler, png_status
+
+
 def inflate_batch_multi(shards, flags=0, gather=True):
     """fdh_inflate_batch_multi from one process: `shards` = one tuple (comp, in_off, out, out_off) of
     tensors per GPU selected by init_devices(); returns per shard (out_len, status, adler) and, with

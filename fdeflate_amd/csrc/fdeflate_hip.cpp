@@ -26,6 +26,12 @@ int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint
 int fdh_launch_deflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                                uint32_t* out_len, uint64_t n, int rle, void* stream_work, void* wave_work, unsigned waves,
                                hipStream_t stream);
+int fdh_launch_png_unfilter(const uint8_t* filt, const uint64_t* filt_off, uint8_t* pix, const uint64_t* pix_off,
+                            uint32_t* status, const uint32_t* gate, uint64_t n, uint32_t row_bytes, uint32_t bpp,
+                            hipStream_t stream);
+int fdh_launch_png_filter(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types, const uint64_t* types_off,
+                          uint8_t* filt, const uint64_t* filt_off, uint32_t* status, uint64_t n, uint32_t row_bytes,
+                          uint32_t bpp, hipStream_t stream);
 size_t fdh_deflate_general_stream_work_bytes(void);
 size_t fdh_deflate_general_wave_work_bytes(void);
 }
@@ -160,6 +166,58 @@ int fdh_debug_build_tables(const uint8_t* code_lengths320, uint32_t hlit, uint32
     int rc = fdh_launch_build_tables_debug(code_lengths320, hlit, litlen4096, dist512, build_status,
                                            static_cast<hipStream_t>(hip_stream));
     if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "table-build kernel launch");
+    return FDH_SUCCESS;
+}
+
+// ---- PNG scanline filters (the steps either side of the codec in the PNG pipeline) ----
+static int png_args_ok(const void* a, const void* b, const void* c, const void* d, const void* st, uint32_t row_bytes,
+                       uint32_t bpp) {
+    if (!a || !b || !c || !d || !st) return fail(FDH_ERR_INVALID_ARGUMENT, "null pointer");
+    if (row_bytes == 0) return fail(FDH_ERR_INVALID_ARGUMENT, "row_bytes must be positive");
+    if (!(bpp == 1 || bpp == 2 || bpp == 3 || bpp == 4 || bpp == 6 || bpp == 8))
+        return fail(FDH_ERR_INVALID_ARGUMENT, "bpp must be 1, 2, 3, 4, 6 or 8 (PNG's whole-byte pixel sizes)");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    return FDH_SUCCESS;
+}
+
+int fdh_png_unfilter_batch(const uint8_t* filt, const uint64_t* filt_off, uint8_t* pix, const uint64_t* pix_off,
+                           uint32_t* png_status, uint64_t n, uint32_t row_bytes, uint32_t bpp, void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    int rc = png_args_ok(filt, filt_off, pix, pix_off, png_status, row_bytes, bpp);
+    if (rc != FDH_SUCCESS) return rc;
+    rc = fdh_launch_png_unfilter(filt, filt_off, pix, pix_off, png_status, nullptr, n, row_bytes, bpp,
+                                 static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "unfilter kernel launch");
+    return FDH_SUCCESS;
+}
+
+int fdh_png_filter_batch(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types, const uint64_t* types_off,
+                         uint8_t* filt, const uint64_t* filt_off, uint32_t* png_status, uint64_t n, uint32_t row_bytes,
+                         uint32_t bpp, void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    int rc = png_args_ok(pix, pix_off, filt, filt_off, png_status, row_bytes, bpp);
+    if (rc != FDH_SUCCESS) return rc;
+    if (!types || !types_off) return fail(FDH_ERR_INVALID_ARGUMENT, "null pointer");
+    rc = fdh_launch_png_filter(pix, pix_off, types, types_off, filt, filt_off, png_status, n, row_bytes, bpp,
+                               static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "filter kernel launch");
+    return FDH_SUCCESS;
+}
+
+int fdh_inflate_png_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* filt, const uint64_t* filt_off,
+                          uint32_t* out_len, uint32_t* status, uint32_t* adler, uint8_t* pix, const uint64_t* pix_off,
+                          uint32_t* png_status, uint64_t n, uint32_t flags, uint32_t row_bytes, uint32_t bpp,
+                          void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    int rc = png_args_ok(filt, filt_off, pix, pix_off, png_status, row_bytes, bpp);
+    if (rc != FDH_SUCCESS) return rc;
+    rc = fdh_inflate_batch(in, in_off, filt, filt_off, out_len, status, adler, n, flags, hip_stream);
+    if (rc != FDH_SUCCESS) return rc;
+    // same stream: the scanlines are reconstructed as soon as the decode kernels have finished, only
+    // for the streams that decoded (status 0) -- the rest gets png_status 3
+    rc = fdh_launch_png_unfilter(filt, filt_off, pix, pix_off, png_status, status, n, row_bytes, bpp,
+                                 static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "unfilter kernel launch");
     return FDH_SUCCESS;
 }
 

@@ -146,6 +146,32 @@ int fdh_deflate_general_batch(const uint8_t *in, const uint64_t *in_off, uint8_t
 /* Slot size that always suffices for the general encoder: len + len / 2 + 1024. */
 uint64_t fdh_compress_bound(uint64_t len);
 
+/* ---- PNG scanline filters: the steps either side of the codec in the PNG pipeline --------
+ * Not in the fdeflate crate (its reverse dependency image-rs/image-png does them, reference
+ * README.md:11); the algorithm is the PNG specification's (W3C / ISO/IEC 15948, 9.2 and 9.4):
+ * filter types 0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth, `bpp` bytes per pixel (1, 2, 3, 4, 6, 8).
+ * One image per lane.  A "filtered" image is rows x (1 + row_bytes) bytes, the type byte first (what
+ * the zlib stream of an IDAT holds); a "pixel" image is rows x row_bytes.  rows_i = size_i / row size.
+ *   fdh_png_unfilter_batch  reconstruction: filt -> pix
+ *   fdh_png_filter_batch    filtering with the given per-row types: pix -> filt (types_off[n+1]
+ *                           into `types`, one byte per row)
+ *   fdh_inflate_png_batch   fdh_inflate_batch into `filt` (the slots must be the exact image sizes)
+ *                           followed, on the same stream, by the reconstruction into `pix` of every
+ *                           stream that decoded
+ * png_status[i]: 0 ok, 1 a filter type > 4, 2 sizes do not fit, 3 skipped (stream did not decode). */
+int fdh_png_unfilter_batch(const uint8_t *filt, const uint64_t *filt_off, uint8_t *pix,
+                           const uint64_t *pix_off, uint32_t *png_status, uint64_t n,
+                           uint32_t row_bytes, uint32_t bpp, void *hip_stream);
+int fdh_png_filter_batch(const uint8_t *pix, const uint64_t *pix_off, const uint8_t *types,
+                         const uint64_t *types_off, uint8_t *filt, const uint64_t *filt_off,
+                         uint32_t *png_status, uint64_t n, uint32_t row_bytes, uint32_t bpp,
+                         void *hip_stream);
+int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *filt,
+                          const uint64_t *filt_off, uint32_t *out_len, uint32_t *status,
+                          uint32_t *adler, uint8_t *pix, const uint64_t *pix_off,
+                          uint32_t *png_status, uint64_t n, uint32_t flags, uint32_t row_bytes,
+                          uint32_t bpp, void *hip_stream);
+
 /* ---- streaming decoder: `Decompressor` (src/decompress.rs:96-156, 179-342) ----------------
  * A host-side object with exactly `Decompressor::read`'s contract on HOST buffers; every bit of
  * decoding is done by fdh_inflate_batch on the device (the object keeps a device-resident copy of

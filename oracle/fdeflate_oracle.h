@@ -119,6 +119,12 @@ size_t fdo_compress_bound(size_t len);
 size_t fdo_compress_level1(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap);
 size_t fdo_compress_rle(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap);
 
+/* ---- PNG scanline filters (PNG specification section 9; the png crate's step either side of the
+ * codec).  filt = rows x (1 + row_bytes) with the filter-type byte first, pix = rows x row_bytes.
+ * Return 0 ok, 1 filter type > 4, 2 size not a whole number of rows. */
+int fdo_png_unfilter(const uint8_t *filt, size_t len, size_t row_bytes, size_t bpp, uint8_t *pix);
+int fdo_png_filter(const uint8_t *pix, size_t len, size_t row_bytes, size_t bpp, const uint8_t *types, uint8_t *filt);
+
 /* ---- batch helpers for the CPU baseline leg (one stream per task, pthreads) ---- */
 void fdo_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
                        const uint64_t *out_off, uint32_t *out_len, uint32_t *status,

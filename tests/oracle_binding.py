@@ -78,6 +78,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.fdo_compress_bound.restype = C.c_size_t
         L.fdo_compress_bound.argtypes = [C.c_size_t]
+        L.fdo_png_unfilter.restype = C.c_int
+        L.fdo_png_unfilter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.fdo_png_filter.restype = C.c_int
+        L.fdo_png_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.fdo_inflate_batch.restype = None
         L.fdo_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
@@ -145,6 +149,24 @@ def compress_level1(data):
 def compress_rle(data):
     """compress_to_vec_rle (src/compress/mod.rs:306)"""
     return _compress_general(lib().fdo_compress_rle, data)
+
+
+def png_unfilter(filt, row_bytes, bpp):
+    """-> (status, pixel bytes)"""
+    a, p = _buf(filt)
+    rows = a.size // (row_bytes + 1)
+    out = np.zeros(max(rows * row_bytes, 1), dtype=np.uint8)
+    st = lib().fdo_png_unfilter(p, a.size, row_bytes, bpp, out.ctypes.data_as(C.c_void_p))
+    return st, out[:rows * row_bytes].tobytes()
+
+
+def png_filter(pix, row_bytes, bpp, types):
+    a, p = _buf(pix)
+    t, tp = _buf(bytes(types))
+    rows = a.size // row_bytes
+    out = np.zeros(max(rows * (row_bytes + 1), 1), dtype=np.uint8)
+    st = lib().fdo_png_filter(p, a.size, row_bytes, bpp, tp, out.ctypes.data_as(C.c_void_p))
+    return st, out[:rows * (row_bytes + 1)].tobytes()
 
 
 def compress_stored(data):

@@ -679,3 +679,61 @@ def test_multi_gpu_entry_points_every_visible_device(harness):
                 assert np.array_equal(m[k, 0, :len(rs)], st) and np.array_equal(m[k, 1, :len(rs)], ol)
     finally:
         fd.shutdown_devices()
+
+
+def test_png_filters_bit_exact_and_fused_decode(harness):
+    """PNG scanline reconstruction / filtering on the GPU (one image per lane)
+    against the oracle's restatement of the PNG specification, for every pixel size and ragged image
+    shapes; then the fused call: ultra-fast streams of filtered images -> decode -> reconstruct."""
+    import torch
+    import fdeflate_amd as fd
+    r = np.random.default_rng(21)
+    for bpp in (1, 2, 3, 4, 6, 8):
+        row_bytes = bpp * int(r.integers(1, 90))
+        pixs, types = [], []
+        for k in range(70):
+            rows = int(r.integers(0, 12))
+            pixs.append(bytes(r.integers(0, 256 if k % 3 else 4, row_bytes * rows, dtype=np.uint8)))
+            types.append(bytes(r.integers(0, 5, rows, dtype=np.uint8)))
+        filts = [ob.png_filter(p, row_bytes, bpp, t)[1] for p, t in zip(pixs, types)]
+        pbuf, poff = streams.pack_exact(pixs)
+        tbuf, toff = streams.pack_exact(types)
+        fbuf, foff = streams.pack_exact(filts)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        d_p, d_po, d_t, d_to = d(pbuf), d(poff.astype(np.int64)), d(tbuf), d(toff.astype(np.int64))
+        d_fo = d(foff.astype(np.int64))
+        d_f = torch.full((max(int(foff[-1]), 1),), 0xEE, dtype=torch.uint8, device="cuda")
+        st = fd.png_filter_batch(d_p, d_po, d_t, d_to, d_f, d_fo, row_bytes, bpp)
+        assert int(st.abs().sum()) == 0 and d_f.cpu().numpy()[:int(foff[-1])].tobytes() == fbuf[:int(foff[-1])].tobytes()
+        d_out = torch.full((max(int(poff[-1]), 1),), 0xEE, dtype=torch.uint8, device="cuda")
+        st = fd.png_unfilter_batch(d(fbuf), d_fo, d_out, d_po, row_bytes, bpp)
+        assert int(st.abs().sum()) == 0 and d_out.cpu().numpy()[:int(poff[-1])].tobytes() == pbuf[:int(poff[-1])].tobytes()
+    # error statuses
+    bad = [bytes([7, 1, 2, 3]), bytes([0, 1, 2])]
+    bbuf, boff = streams.pack_exact(bad)
+    oo = torch.from_numpy(np.array([0, 8, 16], dtype=np.int64)).cuda()
+    st = fd.png_unfilter_batch(torch.from_numpy(bbuf).cuda(), torch.from_numpy(boff.astype(np.int64)).cuda(),
+                               torch.zeros(16, dtype=torch.uint8, device="cuda"), oo, 3, 1)
+    assert st.cpu().tolist() == [1, 2]
+    # fused: 64 x 1023-byte rows with a filter byte each (the bench's buffers), RGB8, plus one broken stream
+    from fdeflate_amd import synth
+    n, rows, rb, bpp = 96, 64, 1023, 3
+    filt_imgs = [synth.gen_stream_np(i, rows * (rb + 1)).tobytes() for i in range(n)]   # type byte 0..4 per row
+    comps = [ob.compress_ultra_fast(f) for f in filt_imgs]
+    comps[5] = comps[5][:-9]
+    cbuf, coff = streams.pack_exact(comps)
+    foff = np.arange(n + 1, dtype=np.int64) * (rows * (rb + 1))
+    poff = np.arange(n + 1, dtype=np.int64) * (rows * rb)
+    d_f = torch.zeros(int(foff[-1]), dtype=torch.uint8, device="cuda")
+    d_p = torch.zeros(int(poff[-1]), dtype=torch.uint8, device="cuda")
+    out_len, status, adler, pst = fd.inflate_png_batch(torch.from_numpy(cbuf).cuda(), torch.from_numpy(coff.astype(np.int64)).cuda(),
+                                                       d_f, torch.from_numpy(foff).cuda(), d_p, torch.from_numpy(poff).cuda(), rb, bpp)
+    torch.cuda.synchronize()
+    stl, psl, hp = status.cpu().tolist(), pst.cpu().tolist(), d_p.cpu().numpy()
+    for i in range(n):
+        if i == 5:
+            assert stl[i] == 2 and psl[i] == 3
+            continue
+        est, epix = ob.png_unfilter(filt_imgs[i], rb, bpp)
+        assert stl[i] == 0 and psl[i] == est == 0
+        assert hp[poff[i]:poff[i + 1]].tobytes() == epix, i

@@ -417,3 +417,32 @@ def test_general_encoder_round_trips_and_structure():
     # RLE mode only ever emits distance 1 (src/compress/parse/rle.rs, matchfinder rle_match)
     d = bytes(np.random.default_rng(3).integers(0, 2, 20000, dtype=np.uint8))
     assert len(ob.compress_rle(d)) < len(d) and len(ob.compress_level1(d)) < len(d)
+
+
+# --------------------------------------------------------------------------------------
+# PNG scanline filters (PNG specification 9.2 / 9.4).  No reference code or
+# vector exists in the tree for this row: pinned by the specification's definitions -- hand-computed
+# cases, the Paeth tie-break order (a, then b, then c), filter -> unfilter round trips for every
+# type and pixel size, and the error returns.
+# --------------------------------------------------------------------------------------
+def test_png_filters_spec_cases_and_round_trips():
+    # Sub then Paeth, bpp 1 (worked by hand from the specification's formulas)
+    assert ob.png_unfilter(bytes([1, 10, 20, 30, 4, 1, 1, 1]), 3, 1) == (0, bytes([10, 30, 60, 11, 31, 61]))
+    # Up and Average with wrap-around, bpp 2: row0 None [250 3 7 9]; row1 Up [10 10 10 10]; row2 Average
+    st, p = ob.png_unfilter(bytes([0, 250, 3, 7, 9, 2, 10, 10, 10, 10, 3, 1, 1, 1, 1]), 4, 2)
+    assert st == 0 and list(p) == [250, 3, 7, 9, 4, 13, 17, 19,
+                                   (1 + (0 + 4) // 2) & 255, (1 + (0 + 13) // 2) & 255,
+                                   (1 + (3 + 17) // 2) & 255, (1 + (7 + 19) // 2) & 255]
+    # Paeth ties: pa == pb == pc -> a ; pb == pc < pa -> b
+    assert ob.png_unfilter(bytes([0, 5, 5, 4, 0, 0]), 2, 1)[1][2:] == bytes([5, 5])
+    r = np.random.default_rng(5)
+    for bpp in (1, 2, 3, 4, 6, 8):
+        for row_bytes in (bpp, bpp * 5, bpp * 21 + 0, 16 * bpp):
+            rows = 11
+            pix = bytes(r.integers(0, 256, row_bytes * rows, dtype=np.uint8))
+            types = [int(x) for x in r.integers(0, 5, rows)]
+            st, f = ob.png_filter(pix, row_bytes, bpp, types)
+            assert st == 0 and len(f) == rows * (row_bytes + 1) and list(f[::row_bytes + 1]) == types
+            assert ob.png_unfilter(f, row_bytes, bpp) == (0, pix)
+    assert ob.png_unfilter(bytes([5, 1, 2, 3]), 3, 1)[0] == 1      # filter type > 4
+    assert ob.png_unfilter(bytes([0, 1, 2]), 3, 1)[0] == 2         # not a whole number of rows
