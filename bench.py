@@ -177,13 +177,36 @@ def native_oracle(native_so):
     return L, how
 
 
+def effective_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (the GPU boxes show 256 logical CPUs but run the job under a 16-CPU quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period) + 0.5))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(q / period + 0.5))
+        except Exception:
+            quota = None
+    return (min(n, quota) if quota else n), n, quota
+
+
 def cpu_baseline(args, comp, c_off, native_so):
     """The oracle (a port of the reference algorithm) and system zlib timed on the host cores over
     a bounded sample of the same workload: threads are created once, every thread decodes >= 64
     streams per pass.  Reported next to the GPU number, never the target."""
     import ctypes as C
     import numpy as np
-    cores = os.cpu_count() or 1
+    cores, visible, quota = effective_cores()
     n, L = args.streams, args.stream_bytes
     k = min(n, max(4096, 64 * cores))                     # bounded sample of the same workload
     end = int(c_off[k])
@@ -213,6 +236,7 @@ def cpu_baseline(args, comp, c_off, native_so):
     z_all, _, _ = timed(cores, 1, k)
     z_one, _, _ = timed(1, 1, k1)
     return {"value": round(all_gbs, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "cpus_visible": visible, "cgroup_cpu_quota": quota,
             "value_1_thread": round(one_gbs, 4),
             "zlib_value": round(z_all, 3), "zlib_value_1_thread": round(z_one, 4),
             "sample": "first %d of the %d streams, %d passes (%.1f GiB decompressed) in %.1f s on %d persistent "
