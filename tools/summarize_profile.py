@@ -60,6 +60,13 @@ if dec:
 if enc:
     step["encode"] = {"hbm_bytes_per_step": enc, "kernels": [k for k in traffic if "deflate" in k],
                       "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes"}
+# bench.py quotes these figures only when they were measured on exactly this kernel source
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    step["kernel_source_sha"] = bench.kernel_source_sha()
+except Exception:
+    pass
 json.dump(step, open(os.path.join(sumdir, "traffic_latest.json"), "w"), indent=1)
 for k, cs in res.items():
     print("pmc", k)
