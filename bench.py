@@ -80,15 +80,22 @@ def launch_ranks(n):
         out = None if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out))
+    # wait for all of them; a rank that dies leaves the others waiting at a collective, so the first
+    # failure ends the run
     rc = 0
-    for p in procs:
-        code = p.wait()
-        if code != 0 and rc == 0:
-            rc = code
-    if rc != 0:
-        for p in procs:   # a failed rank leaves the others waiting at a collective
-            if p.poll() is None:
-                p.kill()
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0:
+                    rc = code
+    for p in live:
+        p.kill()
+    for p in live:
+        p.wait()
     return rc
 
 
@@ -478,6 +485,14 @@ def main():
             except Exception as e:  # the baseline is a reported extra, never fatal
                 res["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        # RCCL prints a version banner through C stdio, which is flushed at exit -- i.e. behind a line
+        # printed from Python.  Flush it out first so that the JSON line is the last line of stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -100,3 +100,20 @@ def test_two_rank_gloo_shard_decode_gather():
         if st == 0:
             assert int(np.uint32(np.int32(meta[r, 2, k]))) == zlib.adler32(raws[i])
     assert int(meta[0, 0, 3]) == 2 and int(meta[0, 0, 5]) == 15
+
+
+def test_bench_launcher_starts_its_own_ranks_and_reports_failure():
+    """`python bench.py --gpus 2` with no rank environment starts two rank processes itself (before
+    any GPU call, free port) and ends when a rank fails: without a GPU in this container both ranks
+    fail at once, the parent must return non-zero promptly instead of waiting at a collective."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--streams", "64", "--no-cpu-baseline", "--no-also"], env=env, capture_output=True, timeout=300)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert p.returncode == 0 and b'"n_gpus": 2' in p.stdout
+    else:
+        assert p.returncode != 0
+        assert time.time() - t0 < 280
