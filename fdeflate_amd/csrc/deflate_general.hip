@@ -1,33 +1,41 @@
 // deflate_general.hip -- the general encoder at level 1 (`compress_to_vec`) and in RLE mode
-// (`compress_to_vec_rle`), bit-exact with the reference, ONE STREAM PER LANE.
+// (`compress_to_vec_rle`), bit-exact with the reference, in two kernels.
 //
 // Reference: Compressor src/compress/mod.rs:47-217 (level 1 = GreedyParser + HashTableMatchFinder
 // :76, RLE = RleParser :107-123), parsers src/compress/parse/{mod,greedy,rle}.rs, match finders
 // src/compress/matchfinder/{mod,hashtable}.rs, block writer src/compress/bitstream.rs:41-325,
 // bit writer src/compress/bitwriter.rs.
 //
-// LZ77 parsing with a hash table is order-dependent inside a stream (every decision depends on
-// what the table held, i.e. on all earlier decisions), so there is nothing for the other 63 lanes
-// of a wavefront to do on the same stream that would not change the bytes.  The batch has tens of
-// thousands of independent streams instead: every lane runs the whole sequential algorithm on its
-// own stream (64 streams per wavefront, the wavefronts hide one another's memory latency).  State
-// that is indexed by data (the 64 Ki-entry hash table, the symbol list of the open block) lives in
-// a per-stream slice of a global workspace; the small per-block arrays (histograms, code lengths,
-// the Huffman heap) are interleaved [index][lane] in the same workspace so that lanes walking them
-// in step touch consecutive addresses.  Nothing is kept in per-lane scratch arrays.
+// 1. deflate_parse_kernel -- ONE STREAM PER LANE.  LZ77 parsing with a hash table is order-dependent
+//    inside a stream (every decision depends on what the table held, i.e. on all earlier decisions),
+//    so the other lanes of a wavefront have nothing to do on the same stream that would not change
+//    the bytes; the batch has thousands of independent streams instead.  Every active lane runs the
+//    reference's parser on its own stream and records what it decided: the back-references (start,
+//    length, distance) in stream order and, whenever the reference would write a block (16384
+//    symbols, bitstream.rs / parse/mod.rs:87-93), where that block ends.  The work is bound by the
+//    latency of dependent loads, not by arithmetic, so the launch uses FEWER lanes per wavefront and
+//    more wavefronts when the batch is small (`lanes`), to have enough wavefronts in flight.
+// 2. deflate_write_kernel -- ONE STREAM PER WAVEFRONT.  Everything the block writer does is a
+//    function of the positions of the block: a position is the start of a back-reference, covered
+//    by one, or a literal.  The wavefront walks the positions 64 at a time (the back-references of
+//    the next 1024 positions are dropped into an LDS array of marks first), once to count symbol
+//    frequencies with LDS atomics, then -- after the Huffman codes are built -- once more to emit:
+//    per-lane bit counts are prefix-summed and every lane ORs its code into the LDS bit ring
+//    (bit_ring.h).  The Adler-32 rides on the second walk.
 //
-// The tie-breaking of the Huffman construction follows Rust's BinaryHeap exactly as the reference
-// uses it (see the oracle's section header for what is pinned and what is not).
+// The Huffman construction follows Rust's BinaryHeap exactly as the reference uses it (see the
+// oracle's section header for what is pinned and what is not); the order-dependent part (heap
+// merges) runs on one lane per tree -- the literal/length and the distance tree side by side on
+// lanes 0 and 1 -- the rest (compaction, code assignment, header) on the whole wavefront.
 #include "device_common.h"
+#include "bit_ring.h"
 
 namespace fdh {
 
 // ---- constant tables (RFC 1951; reference src/tables.rs:28-88, data) -----------------------
 __device__ static const uint8_t kGDistLookup[16] = {0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7};
-__device__ static const uint32_t kGBitmask[17] = {0x0000, 0x0001, 0x0003, 0x0007, 0x000F, 0x001F, 0x003F, 0x007F, 0x00FF,
-                                                  0x01FF, 0x03FF, 0x07FF, 0x0FFF, 0x1FFF, 0x3FFF, 0x7FFF, 0xFFFF};
 
-// length - 3 -> (symbol - 257, extra bits): LENGTH_TO_SYMBOL / LENGTH_TO_LEN_EXTRA (tables.rs:28-55)
+// length - 3 -> (symbol, extra bits): LENGTH_TO_SYMBOL / LENGTH_TO_LEN_EXTRA (tables.rs:28-55)
 __device__ __forceinline__ void g_length_symbol(uint32_t length, uint32_t& sym, uint32_t& extra) {
     const uint32_t l = length - 3;
     if (l == 255) {  // 258
@@ -45,78 +53,27 @@ __device__ __forceinline__ void g_length_symbol(uint32_t length, uint32_t& sym, 
     extra = e;
 }
 
-constexpr uint32_t kGMaxSymbols = 16384 + 8;
 constexpr uint32_t kGHashSize = 1u << 16;
+constexpr uint32_t kGBlockSymbols = 16384;
 
-struct GSym {
-    uint32_t a;  // literal run: start          | back-reference: 0x80000000 | length
-    uint32_t b;  // literal run: end            | back-reference: distance | dist_sym << 16
+// What the parser hands to the block writer.  Back-references never overlap and are at least 4
+// bytes long, so a stream of `len` bytes has at most len / 4 of them; a block that is not the last
+// one holds 16384 symbols of at least one byte each.  The per-stream slices of the two record
+// arrays are placed with these bounds straight from in_off (no prefix sum needed).
+struct GMatchRec {
+    uint32_t start;  // position in the stream
+    uint32_t info;   // length | dist_sym << 9 | (distance - 1) << 14
 };
-
-// Per-stream slice of the workspace (data-indexed state).
-struct GStreamWork {
-    uint32_t hash[kGHashSize];
-    GSym symbols[kGMaxSymbols];
+struct GBlockRec {
+    uint32_t end_pos;    // the block covers positions [end of the previous block, end_pos)
+    uint32_t match_end;  // and back-references [match_end of the previous block, match_end)
+    uint32_t flags;
+    uint32_t pad;
 };
-// Per-wavefront block of small arrays, interleaved [index][lane].
-struct GWaveWork {
-    uint32_t freq[286][kWave], dfreq[30][kWave], clfreq[19][kWave];
-    uint8_t lengths[286][kWave], dlengths[30][kWave], cllengths[19][kWave];
-    uint16_t codes[286][kWave], dcodes[30][kWave], clcodes[19][kWave];
-    uint32_t heap_f[286][kWave];
-    uint16_t heap_i[286][kWave];
-    uint16_t in_left[286][kWave], in_right[286][kWave];
-    uint16_t stack_node[600][kWave];
-    uint8_t stack_depth[600][kWave];
-    uint16_t order[286][kWave];
-    uint32_t counts[16][kWave];
-};
-
-struct GBitWriter {  // bitwriter.rs:3-51 over a bounded slot
-    uint64_t buffer;
-    uint32_t nbits;
-    uint8_t* out;
-    uint64_t cap, pos;
-    bool overflow;
-    __device__ void raw(const void* p, uint32_t n) {
-        if (pos + n > cap) {
-            overflow = true;
-            return;
-        }
-        const uint8_t* s = static_cast<const uint8_t*>(p);
-        for (uint32_t i = 0; i < n; i++) out[pos + i] = s[i];
-        pos += n;
-    }
-    __device__ void write_bits(uint64_t bits, uint32_t n) {
-        buffer |= bits << nbits;
-        nbits += n;
-        if (nbits >= 64) {
-            if (pos + 8 > cap) {
-                overflow = true;
-            } else {
-                for (int i = 0; i < 8; i++) out[pos + i] = (uint8_t)(buffer >> (8 * i));
-                pos += 8;
-            }
-            nbits -= 64;
-            const uint32_t sh = n - nbits;
-            buffer = sh >= 64 ? 0 : bits >> sh;
-        }
-    }
-    __device__ void flush() {
-        if (nbits % 8 != 0) write_bits(0, 8 - nbits % 8);
-        if (nbits > 0) {
-            const uint32_t n = nbits / 8;
-            if (pos + n > cap) {
-                overflow = true;
-            } else {
-                for (uint32_t i = 0; i < n; i++) out[pos + i] = (uint8_t)(buffer >> (8 * i));
-                pos += n;
-            }
-            buffer = 0;
-            nbits = 0;
-        }
-    }
-};
+constexpr uint32_t kGBlockEof = 1;         // BFINAL
+constexpr uint32_t kGBlockEmptyFixed = 2;  // the empty fixed block of compress/mod.rs:234-238
+__host__ __device__ inline uint64_t g_match_slice(uint64_t rel_off, uint64_t i) { return rel_off / 4 + 2 * i; }
+__host__ __device__ inline uint64_t g_block_slice(uint64_t rel_off, uint64_t i) { return rel_off / kGBlockSymbols + 4 * i; }
 
 __device__ __forceinline__ uint64_t g_load64(const uint8_t* p) {
     uint64_t v;
@@ -131,194 +88,14 @@ struct GMatch {
     __device__ uint64_t end() const { return start + length; }
 };
 
-// ---- build_huffman_tree (bitstream.rs:198-325) on interleaved arrays -----------------------
-// Ord of the heap items: `other.0.cmp(&self.0)`: a <= b  <=>  a.f >= b.f (ties decided by the
-// std::collections::BinaryHeap algorithms restated below).
-template <int N>
-struct GHuff {
-    uint32_t (*freq)[kWave];
-    uint8_t (*lengths)[kWave];
-    uint16_t (*codes)[kWave];
-    GWaveWork* w;
-    int lane;
-
-    __device__ void sift_down_range(uint32_t pos, uint32_t end) {
-        const uint32_t ef = w->heap_f[pos][lane];
-        const uint16_t ei = w->heap_i[pos][lane];
-        uint32_t hole = pos, child = 2 * hole + 1;
-        const uint32_t lim = end >= 2 ? end - 2 : 0;
-        while (child <= lim) {
-            if (w->heap_f[child][lane] >= w->heap_f[child + 1][lane]) child++;  // d[child] <= d[child + 1]
-            if (ef <= w->heap_f[child][lane]) {                                 // elem >= d[child]
-                w->heap_f[hole][lane] = ef;
-                w->heap_i[hole][lane] = ei;
-                return;
-            }
-            w->heap_f[hole][lane] = w->heap_f[child][lane];
-            w->heap_i[hole][lane] = w->heap_i[child][lane];
-            hole = child;
-            child = 2 * hole + 1;
-        }
-        if (child == end - 1 && ef > w->heap_f[child][lane]) {  // elem < d[child]
-            w->heap_f[hole][lane] = w->heap_f[child][lane];
-            w->heap_i[hole][lane] = w->heap_i[child][lane];
-            hole = child;
-        }
-        w->heap_f[hole][lane] = ef;
-        w->heap_i[hole][lane] = ei;
-    }
-    // BinaryHeap::pop: swap the last item into the root, sift_down_to_bottom(0), sift_up
-    __device__ void pop(uint32_t& len, uint32_t& f, uint16_t& idx) {
-        uint32_t lf = w->heap_f[len - 1][lane];
-        uint16_t li = w->heap_i[len - 1][lane];
-        len--;
-        if (len == 0) {
-            f = lf;
-            idx = li;
-            return;
-        }
-        f = w->heap_f[0][lane];
-        idx = w->heap_i[0][lane];
-        const uint32_t end = len;
-        uint32_t hole = 0, child = 1;
-        const uint32_t lim = end >= 2 ? end - 2 : 0;
-        while (child <= lim) {
-            if (w->heap_f[child][lane] >= w->heap_f[child + 1][lane]) child++;
-            w->heap_f[hole][lane] = w->heap_f[child][lane];
-            w->heap_i[hole][lane] = w->heap_i[child][lane];
-            hole = child;
-            child = 2 * hole + 1;
-        }
-        if (child == end - 1) {
-            w->heap_f[hole][lane] = w->heap_f[child][lane];
-            w->heap_i[hole][lane] = w->heap_i[child][lane];
-            hole = child;
-        }
-        while (hole > 0) {  // sift_up(0, hole)
-            const uint32_t parent = (hole - 1) / 2;
-            if (lf >= w->heap_f[parent][lane]) break;  // elem <= d[parent]
-            w->heap_f[hole][lane] = w->heap_f[parent][lane];
-            w->heap_i[hole][lane] = w->heap_i[parent][lane];
-            hole = parent;
-        }
-        w->heap_f[hole][lane] = lf;
-        w->heap_i[hole][lane] = li;
-    }
-
-    __device__ void build(uint32_t length_limit) {
-        uint32_t used = 0, first = 0;
-        for (int i = 0; i < N; i++) {
-            lengths[i][lane] = 0;
-            codes[i][lane] = 0;
-            if (freq[i][lane] > 0) {
-                if (used == 0) first = (uint32_t)i;
-                used++;
-            }
-        }
-        if (used <= 1) {  // :206-213
-            if (used == 1) lengths[first][lane] = 1;
-            return;
-        }
-        uint32_t hl = 0, ni = 0;
-        for (int i = 0; i < N; i++) {
-            const uint32_t f = freq[i][lane];
-            if (f > 0) {
-                w->heap_f[hl][lane] = f;
-                w->heap_i[hl][lane] = (uint16_t)i;
-                hl++;
-            }
-        }
-        for (uint32_t k = hl / 2; k > 0;) {  // BinaryHeap::from(vec): rebuild
-            k--;
-            sift_down_range(k, hl);
-        }
-        while (hl > 1) {  // :236-244
-            uint32_t f1;
-            uint16_t i1;
-            pop(hl, f1, i1);
-            w->in_left[ni][lane] = i1;
-            w->in_right[ni][lane] = w->heap_i[0][lane];
-            ni++;
-            w->heap_f[0][lane] = f1 + w->heap_f[0][lane];
-            w->heap_i[0][lane] = (uint16_t)(ni + N - 1);
-            sift_down_range(0, hl);  // PeekMut::drop
-        }
-        // :247-259 walk the tree
-        uint32_t sp = 0;
-        w->stack_node[0][lane] = w->heap_i[0][lane];
-        w->stack_depth[0][lane] = 0;
-        sp = 1;
-        uint32_t max_length = 0;
-        while (sp > 0) {
-            sp--;
-            const uint32_t node = w->stack_node[sp][lane];
-            const uint32_t depth = w->stack_depth[sp][lane];
-            if (node < (uint32_t)N) {
-                lengths[node][lane] = (uint8_t)depth;
-                max_length = max(max_length, depth);
-            } else {
-                w->stack_node[sp][lane] = w->in_left[node - N][lane];
-                w->stack_depth[sp][lane] = (uint8_t)(depth + 1);
-                sp++;
-                w->stack_node[sp][lane] = w->in_right[node - N][lane];
-                w->stack_depth[sp][lane] = (uint8_t)(depth + 1);
-                sp++;
-            }
-        }
-        if (max_length > length_limit) {  // :262-305
-            for (int i = 0; i < 16; i++) w->counts[i][lane] = 0;
-            for (int i = 0; i < N; i++) w->counts[min((uint32_t)lengths[i][lane], length_limit)][lane]++;
-            uint32_t total = 0;
-            for (uint32_t i = 1; i <= length_limit; i++) total += w->counts[i][lane] << (length_limit - i);
-            while (total > (1u << length_limit)) {
-                uint32_t i = length_limit - 1;
-                while (w->counts[i][lane] == 0) i--;
-                w->counts[i][lane]--;
-                w->counts[length_limit][lane]--;
-                w->counts[i + 1][lane] += 2;
-                total--;
-            }
-            // by frequency, ties in index order (insertion sort = what sort_unstable does up to 20
-            // elements; beyond that the reference's tie order is implementation-defined)
-            for (int i = 0; i < N; i++) w->order[i][lane] = (uint16_t)i;
-            for (int i = 1; i < N; i++) {
-                const uint16_t v = w->order[i][lane];
-                const uint32_t fv = freq[v][lane];
-                int j = i;
-                while (j > 0 && freq[w->order[j - 1][lane]][lane] > fv) {
-                    w->order[j][lane] = w->order[j - 1][lane];
-                    j--;
-                }
-                w->order[j][lane] = v;
-            }
-            uint32_t len = length_limit;
-            for (int k = 0; k < N; k++) {
-                const uint32_t i = w->order[k][lane];
-                if (freq[i][lane] > 0) {
-                    while (w->counts[len][lane] == 0) len--;
-                    lengths[i][lane] = (uint8_t)len;
-                    w->counts[len][lane]--;
-                }
-            }
-        }
-        uint32_t code = 0;  // :308-320 canonical codes, bit-reversed
-        for (uint32_t len = 1; len <= length_limit; len++) {
-            for (int i = 0; i < N; i++) {
-                if (lengths[i][lane] == len) {
-                    codes[i][lane] = (uint16_t)(__brev(code) >> (32 - len));
-                    code++;
-                }
-            }
-            code <<= 1;
-        }
-    }
-};
+// ============================ kernel 1: the parser, one stream per lane ============================
 
 struct GParser {
-    GStreamWork* sw;
-    GWaveWork* ww;
-    int lane;
-    uint32_t nsym;
+    uint32_t* hash;     // this lane's table (level 1)
+    GMatchRec* mrec;    // this stream's slices
+    GBlockRec* brec;
+    uint32_t nmatch, nblock;
+    uint32_t nsym;      // symbols (literal runs + back-references) of the open block
     uint64_t ip, last_match, last_block_end;
     uint32_t last_index;
     GMatch m;
@@ -329,69 +106,6 @@ struct GParser {
         uint32_t s = 29;
         while (s > 0 && distance < kDistBase[s]) s--;
         return s;
-    }
-
-    // write_block (bitstream.rs:41-195)
-    __device__ void write_block(GBitWriter& bw, const uint8_t* data, uint32_t base_index, bool eof) {
-        for (int i = 0; i < 286; i++) ww->freq[i][lane] = 0;
-        for (int i = 0; i < 30; i++) ww->dfreq[i][lane] = 0;
-        for (int i = 0; i < 19; i++) ww->clfreq[i][lane] = 0;
-        ww->freq[256][lane] = 1;
-        for (uint32_t k = 0; k < nsym; k++) {
-            const GSym s = sw->symbols[k];
-            if (s.a & 0x80000000u) {
-                uint32_t sym, extra;
-                g_length_symbol(s.a & 0xFFFF, sym, extra);
-                ww->freq[sym][lane]++;
-                ww->dfreq[s.b >> 16][lane]++;
-            } else {
-                for (uint32_t p = s.a - base_index; p < s.b - base_index; p++) ww->freq[data[p]][lane]++;
-            }
-        }
-        GHuff<286> hl{ww->freq, ww->lengths, ww->codes, ww, lane};
-        hl.build(15);
-        GHuff<30> hd{ww->dfreq, ww->dlengths, ww->dcodes, ww, lane};
-        hd.build(15);
-        uint32_t num_litlen = 286, num_dist = 30;
-        while (num_litlen > 257 && ww->lengths[num_litlen - 1][lane] == 0) num_litlen--;
-        while (num_dist > 1 && ww->dlengths[num_dist - 1][lane] == 0) num_dist--;
-        for (uint32_t i = 0; i < num_litlen; i++) ww->clfreq[ww->lengths[i][lane]][lane]++;
-        for (uint32_t i = 0; i < num_dist; i++) ww->clfreq[ww->dlengths[i][lane]][lane]++;
-        GHuff<19> hc{ww->clfreq, ww->cllengths, ww->clcodes, ww, lane};
-        hc.build(7);
-
-        bw.write_bits(eof ? 5 : 4, 3);
-        bw.write_bits(num_litlen - 257, 5);
-        bw.write_bits(num_dist - 1, 5);
-        bw.write_bits(15, 4);
-        for (int j = 0; j < 19; j++) bw.write_bits(ww->cllengths[kClclOrder[j]][lane], 3);
-        for (uint32_t i = 0; i < num_litlen; i++) {
-            const uint32_t l = ww->lengths[i][lane];
-            bw.write_bits(ww->clcodes[l][lane], ww->cllengths[l][lane]);
-        }
-        for (uint32_t i = 0; i < num_dist; i++) {
-            const uint32_t l = ww->dlengths[i][lane];
-            bw.write_bits(ww->clcodes[l][lane], ww->cllengths[l][lane]);
-        }
-        for (uint32_t k = 0; k < nsym; k++) {
-            const GSym s = sw->symbols[k];
-            if (s.a & 0x80000000u) {
-                const uint32_t length = s.a & 0xFFFF, distance = s.b & 0xFFFF, ds = s.b >> 16;
-                uint32_t sym, extra;
-                g_length_symbol(length, sym, extra);
-                bw.write_bits(ww->codes[sym][lane], ww->lengths[sym][lane]);
-                bw.write_bits((length - 3) & kGBitmask[extra], extra);
-                bw.write_bits(ww->dcodes[ds][lane], ww->dlengths[ds][lane]);
-                bw.write_bits(distance - kDistBase[ds], kDistExtra[ds]);
-            } else {
-                // (the reference packs four literals per write_bits, :134-160: the byte stream is the same)
-                for (uint32_t p = s.a - base_index; p < s.b - base_index; p++) {
-                    const uint32_t c = data[p];
-                    bw.write_bits(ww->codes[c][lane], ww->lengths[c][lane]);
-                }
-            }
-        }
-        bw.write_bits(ww->codes[256][lane], ww->lengths[256][lane]);
     }
 
     // match_length::<true> (matchfinder/mod.rs:51-111)
@@ -480,8 +194,8 @@ struct GParser {
             const uint32_t sub = (uint32_t)ip > 32768 ? (uint32_t)ip - 32768 : 0;
             const uint32_t min_offset = max(base_index + sub, 1u);
             const uint32_t h = g_hash(current);
-            const uint32_t offset = sw->hash[h];
-            sw->hash[h] = (uint32_t)ip + base_index;
+            const uint32_t offset = hash[h];
+            hash[h] = (uint32_t)ip + base_index;
             if (offset >= min_offset) {
                 uint32_t l;
                 uint64_t st;
@@ -514,24 +228,28 @@ struct GParser {
     __device__ void advance(const uint8_t* data, uint64_t len, uint32_t base_index, uint64_t end) {
         if (!RLE) {
             const uint64_t stop = min(end, len - 8);
-            for (uint64_t j = ip; j < stop; j++) sw->hash[g_hash(g_load64(data + j))] = base_index + (uint32_t)j;
+            for (uint64_t j = ip; j < stop; j++) hash[g_hash(g_load64(data + j))] = base_index + (uint32_t)j;
         }
         ip = max(ip, end);
     }
 
+    // where write_block (bitstream.rs:41-195) would run: the block ends at `end` (absolute)
+    __device__ void record_block(uint32_t end, uint32_t flags) {
+        brec[nblock] = GBlockRec{end, nmatch, flags, 0};
+        nblock++;
+    }
+
     __device__ void insert_match(uint32_t base_index, const GMatch& r) {
-        if (r.start > last_match) {
-            sw->symbols[nsym] = GSym{base_index + (uint32_t)last_match, base_index + (uint32_t)r.start};
-            nsym++;
-        }
-        sw->symbols[nsym] = GSym{0x80000000u | r.length, r.distance | (dist_sym_of(r.distance) << 16)};
+        if (r.start > last_match) nsym++;  // the literal run in front of it
+        mrec[nmatch] = GMatchRec{base_index + (uint32_t)r.start, r.length | (dist_sym_of(r.distance) << 9) | ((r.distance - 1) << 14)};
+        nmatch++;
         nsym++;
         last_match = r.end();
     }
 
-    __device__ void write_block_if_ready(GBitWriter& bw, const uint8_t* data, uint64_t len, uint32_t base_index, bool finish) {
-        if (nsym >= 16384) {
-            write_block(bw, data, base_index, finish && last_match == len);
+    __device__ void write_block_if_ready(uint64_t len, uint32_t base_index, bool finish) {
+        if (nsym >= kGBlockSymbols) {
+            record_block(base_index + (uint32_t)last_match, finish && last_match == len ? kGBlockEof : 0);
             nsym = 0;
             last_block_end = last_match;
         }
@@ -546,17 +264,15 @@ struct GParser {
         return delta;
     }
 
-    __device__ uint64_t end_compress(GBitWriter& bw, const uint8_t* data, uint64_t len, uint32_t base_index, uint64_t start,
-                                     bool finish) {
+    __device__ uint64_t end_compress(uint64_t len, uint32_t base_index, uint64_t start, bool finish) {
         if (finish && (nsym != 0 || last_match < len)) {
             ip = min(ip, len);
-            if (last_match < len) {
-                sw->symbols[nsym] = GSym{base_index + (uint32_t)last_match, base_index + (uint32_t)len};
+            if (last_match < len) {  // the closing literal run
                 nsym++;
                 ip = len;
                 last_match = len;
             }
-            write_block(bw, data, base_index, true);
+            record_block(base_index + (uint32_t)len, kGBlockEof);
             nsym = 0;
             last_block_end = ip;
         }
@@ -566,11 +282,9 @@ struct GParser {
     // CompressorInner::compress (compress/mod.rs:226-290) -> GreedyParser::compress
     // (parse/greedy.rs:27-91) / RleParser::compress (parse/rle.rs:22-47)
     template <bool RLE>
-    __device__ uint64_t compress(GBitWriter& bw, const uint8_t* data, uint64_t len, uint32_t base_index, uint64_t start,
-                                 bool finish) {
+    __device__ uint64_t compress(const uint8_t* data, uint64_t len, uint32_t base_index, uint64_t start, bool finish) {
         if (finish && len == start) {  // :234-238
-            bw.write_bits(3, 10);
-            bw.flush();
+            record_block(base_index + (uint32_t)len, kGBlockEmptyFixed);
             return 0;
         }
         const uint64_t delta = start_compress(base_index, start);
@@ -583,7 +297,7 @@ struct GParser {
                 if (r.length == 0) break;
                 ip = r.end();
                 insert_match(base_index, r);
-                write_block_if_ready(bw, data, len, base_index, finish);
+                write_block_if_ready(len, base_index, finish);
             }
         } else {
             for (;;) {
@@ -600,7 +314,7 @@ struct GParser {
                 }
                 if (m2.length == 0 || m2.start > m.start + 1) {
                     insert_match(base_index, m);
-                    write_block_if_ready(bw, data, len, base_index, finish);
+                    write_block_if_ready(len, base_index, finish);
                     if (m2.length != 0 && m2.start < last_match) {
                         m2.length -= (uint32_t)(last_match - m2.start);
                         m2.start = last_match;
@@ -610,101 +324,554 @@ struct GParser {
                 m = m2;
             }
         }
-        return end_compress(bw, data, len, base_index, start, finish);
+        return end_compress(len, base_index, start, finish);
     }
 };
 
-struct DeflateGeneralArgs {
+struct GParseArgs {
+    const uint8_t* in;
+    const uint64_t* in_off;
+    uint64_t n;
+    uint32_t* hash;      // kGHashSize entries per resident lane (level 1)
+    GMatchRec* matches;  // slices by g_match_slice
+    GBlockRec* blocks;   // slices by g_block_slice
+    uint32_t* nblocks;   // per stream; 0xFFFFFFFF = not supported (longer than 1 GiB)
+    uint32_t lanes;      // streams per wavefront (1..64)
+};
+
+template <bool RLE>
+__global__ __launch_bounds__(kWave) void deflate_parse_kernel(GParseArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t L = a.lanes;
+    const uint64_t in0 = a.in_off[0];
+    uint32_t* wave_hash = RLE ? nullptr : a.hash + (uint64_t)blockIdx.x * L * kGHashSize;
+    for (uint64_t sid0 = (uint64_t)blockIdx.x * L; sid0 < a.n; sid0 += (uint64_t)gridDim.x * L) {
+        if (!RLE) {
+            // HashTableMatchFinder::new (hashtable.rs:10-14): the tables of the wavefront's streams
+            // are cleared by the whole wavefront (coalesced 16-B stores), not lane by lane
+            uint4* t = reinterpret_cast<uint4*>(wave_hash);
+            for (uint32_t i = lane; i < L * (kGHashSize / 4); i += kWave) t[i] = make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint64_t sid = sid0 + lane;
+        if (lane >= L || sid >= a.n) continue;
+        const uint64_t off = a.in_off[sid];
+        const uint8_t* input = a.in + off;
+        const uint64_t len = a.in_off[sid + 1] - off;
+        if (len > (1ull << 30)) {  // write_data splits above 1 GiB (compress/mod.rs:130-136): not supported
+            a.nblocks[sid] = 0xFFFFFFFFu;
+            continue;
+        }
+        GParser ps;
+        ps.hash = RLE ? nullptr : wave_hash + (uint64_t)lane * kGHashSize;
+        ps.mrec = a.matches + g_match_slice(off - in0, sid);
+        ps.brec = a.blocks + g_block_slice(off - in0, sid);
+        ps.nmatch = ps.nblock = ps.nsym = 0;
+        ps.ip = ps.last_match = ps.last_block_end = 0;
+        ps.last_index = 0;
+        ps.m = GMatch{0, 0, 0};
+        const uint64_t window = RLE ? 1 : 32768;
+        // Compressor::write_data (compress/mod.rs:126-159, no buffered input) ...
+        const uint64_t written = ps.compress<RLE>(input, len, 0, 0, false);
+        const uint64_t start = written > window ? written - window : 0;
+        // ... and Compressor::finish (:194-214) over the kept tail input.data = data[start..]
+        ps.compress<RLE>(input + start, len - start, (uint32_t)start, written - start, true);
+        a.nblocks[sid] = ps.nblock;
+    }
+}
+
+// ============================ kernel 2: the block writer, one stream per wavefront ============================
+
+constexpr uint32_t kGChunk = 1024;  // positions per refill of the marks
+
+// Scratch of one Huffman construction (build_huffman_tree, bitstream.rs:198-325).
+template <int CAP>
+struct GHuffScratch {
+    uint64_t heap[CAP];        // frequency << 32 | node index
+    uint16_t in_left[CAP], in_right[CAP];
+    uint8_t depth[CAP];        // of the internal nodes
+    uint8_t lengths[CAP];
+    uint16_t order[CAP];
+    uint32_t counts[16], first[16];
+    uint32_t heap_len, used, max_length, pad;
+};
+
+struct GHuffView {  // the same code runs on two lanes over different trees
+    uint32_t* freq;
+    uint64_t* heap;
+    uint16_t *in_left, *in_right, *order;
+    uint8_t *depth, *lengths;
+    uint32_t *counts, *hdr;  // hdr[0] heap_len, [1] used, [2] max_length
+    uint32_t n, limit;
+};
+
+template <int CAP>
+__device__ __forceinline__ GHuffView g_view(GHuffScratch<CAP>& s, uint32_t* freq, uint32_t n, uint32_t limit) {
+    return GHuffView{freq, s.heap, s.in_left, s.in_right, s.order, s.depth, s.lengths, s.counts, &s.heap_len, n, limit};
+}
+
+struct GWriteLds {
+    uint32_t ring[kEncRingDw];
+    uint32_t freq[288], dfreq[32], clfreq[20];
+    uint32_t cl[288], dcl[32], clcl[20];  // code | length << 16
+    uint32_t dmeta[32];                   // distance base | extra bits << 16
+    union {
+        uint32_t marks[kGChunk];  // info of the back-reference that starts at a position of the chunk, else 0
+        struct {
+            GHuffScratch<288> big;
+            GHuffScratch<32> small;
+        } h;
+    };
+};
+
+// Ord of the heap items is `other.0.cmp(&self.0)` on the frequency only: a <= b  <=>  a.f >= b.f;
+// ties are decided by the std::collections::BinaryHeap algorithms restated below.
+__device__ __forceinline__ uint32_t hf(uint64_t item) { return (uint32_t)(item >> 32); }
+
+__device__ void g_sift_down_range(uint64_t* d, uint32_t pos, uint32_t end) {
+    const uint64_t elem = d[pos];
+    uint32_t hole = pos, child = 2 * hole + 1;
+    const uint32_t lim = end >= 2 ? end - 2 : 0;
+    while (child <= lim) {
+        const uint64_t c0 = d[child], c1 = d[child + 1];
+        const bool right = hf(c0) >= hf(c1);  // d[child] <= d[child + 1]
+        const uint64_t c = right ? c1 : c0;
+        child += right;
+        if (hf(elem) <= hf(c)) {  // elem >= d[child]
+            d[hole] = elem;
+            return;
+        }
+        d[hole] = c;
+        hole = child;
+        child = 2 * hole + 1;
+    }
+    if (child == end - 1) {
+        const uint64_t c = d[child];
+        if (hf(elem) > hf(c)) {  // elem < d[child]
+            d[hole] = c;
+            hole = child;
+        }
+    }
+    d[hole] = elem;
+}
+
+// BinaryHeap::pop: the last item goes to the root, sift_down_to_bottom(0), then sift_up
+__device__ uint64_t g_heap_pop(uint64_t* d, uint32_t& len) {
+    const uint64_t last = d[len - 1];
+    len--;
+    if (len == 0) return last;
+    const uint64_t top = d[0];
+    const uint32_t end = len;
+    uint32_t hole = 0, child = 1;
+    const uint32_t lim = end >= 2 ? end - 2 : 0;
+    while (child <= lim) {
+        const uint64_t c0 = d[child], c1 = d[child + 1];
+        const bool right = hf(c0) >= hf(c1);
+        d[hole] = right ? c1 : c0;
+        child += right;
+        hole = child;
+        child = 2 * hole + 1;
+    }
+    if (child == end - 1) {
+        d[hole] = d[child];
+        hole = child;
+    }
+    while (hole > 0) {  // sift_up(0, hole)
+        const uint32_t parent = (hole - 1) / 2;
+        const uint64_t p = d[parent];
+        if (hf(last) >= hf(p)) break;  // elem <= d[parent]
+        d[hole] = p;
+        hole = parent;
+    }
+    d[hole] = last;
+    return top;
+}
+
+// Whole wavefront: clear the lengths, put the used symbols on the heap array in index order
+// (bitstream.rs:200-222: `for (i, &f) in frequencies.iter().enumerate()` pushes in that order).
+__device__ void g_huff_prepare(const GHuffView& v, int lane) {
+    uint32_t hl = 0;
+    for (uint32_t base = 0; base < v.n; base += kWave) {
+        const uint32_t i = base + lane;
+        const uint32_t f = i < v.n ? v.freq[i] : 0;
+        if (i < v.n) v.lengths[i] = 0;
+        const uint64_t m = __ballot(f > 0);
+        if (f > 0) v.heap[hl + __popcll(m & lanemask_lt(lane))] = ((uint64_t)f << 32) | i;
+        hl += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) {
+        v.hdr[0] = hl;
+        v.hdr[1] = hl;
+        v.hdr[2] = 0;
+    }
+}
+
+// One lane: the order-dependent part -- heapify, merge, depths, length limiting.
+__device__ void g_huff_serial(const GHuffView& v) {
+    const uint32_t N = v.n;
+    uint32_t hl = v.hdr[0];
+    if (hl <= 1) {  // :206-213 nothing or a single symbol (length 1)
+        if (hl == 1) {
+            v.lengths[(uint32_t)v.heap[0] & 0xFFFF] = 1;
+            v.hdr[2] = 1;
+        }
+        return;
+    }
+    for (uint32_t k = hl / 2; k > 0;) {  // BinaryHeap::from(vec): rebuild
+        k--;
+        g_sift_down_range(v.heap, k, hl);
+    }
+    uint32_t ni = 0;
+    while (hl > 1) {  // :236-244
+        const uint64_t a = g_heap_pop(v.heap, hl);
+        const uint64_t b = v.heap[0];
+        v.in_left[ni] = (uint16_t)a;
+        v.in_right[ni] = (uint16_t)b;
+        ni++;
+        v.heap[0] = ((uint64_t)(hf(a) + hf(b)) << 32) | (ni + N - 1);
+        g_sift_down_range(v.heap, 0, hl);  // PeekMut::drop
+    }
+    // :247-259 depth of every leaf; a node is always created after its children, so one pass from
+    // the root (the last internal node) down the creation order visits parents first
+    uint32_t max_length = 0;
+    v.depth[ni - 1] = 0;
+    for (uint32_t k = ni; k > 0;) {
+        k--;
+        const uint32_t dch = (uint32_t)v.depth[k] + 1;
+        const uint32_t l = v.in_left[k], r = v.in_right[k];
+        if (l < N) {
+            v.lengths[l] = (uint8_t)dch;
+            max_length = max(max_length, dch);
+        } else {
+            v.depth[l - N] = (uint8_t)dch;
+        }
+        if (r < N) {
+            v.lengths[r] = (uint8_t)dch;
+            max_length = max(max_length, dch);
+        } else {
+            v.depth[r - N] = (uint8_t)dch;
+        }
+    }
+    const uint32_t limit = v.limit;
+    if (max_length > limit) {  // :262-305
+        for (int i = 0; i < 16; i++) v.counts[i] = 0;
+        for (uint32_t i = 0; i < N; i++) v.counts[min((uint32_t)v.lengths[i], limit)]++;
+        uint32_t total = 0;
+        for (uint32_t i = 1; i <= limit; i++) total += v.counts[i] << (limit - i);
+        while (total > (1u << limit)) {
+            uint32_t i = limit - 1;
+            while (v.counts[i] == 0) i--;
+            v.counts[i]--;
+            v.counts[limit]--;
+            v.counts[i + 1] += 2;
+            total--;
+        }
+        // by frequency, ties in index order (insertion sort = what sort_unstable does up to 20
+        // elements; beyond that the reference's tie order is implementation-defined)
+        for (uint32_t i = 0; i < N; i++) v.order[i] = (uint16_t)i;
+        for (uint32_t i = 1; i < N; i++) {
+            const uint16_t x = v.order[i];
+            const uint32_t fx = v.freq[x];
+            uint32_t j = i;
+            while (j > 0 && v.freq[v.order[j - 1]] > fx) {
+                v.order[j] = v.order[j - 1];
+                j--;
+            }
+            v.order[j] = x;
+        }
+        uint32_t len = limit;
+        for (uint32_t k = 0; k < N; k++) {
+            const uint32_t i = v.order[k];
+            if (v.freq[i] > 0) {
+                while (v.counts[len] == 0) len--;
+                v.lengths[i] = (uint8_t)len;
+                v.counts[len]--;
+            }
+        }
+        max_length = limit;
+    }
+    v.hdr[2] = max_length;
+}
+
+// Whole wavefront: canonical codes, bit-reversed (:308-320), as code | length << 16.
+__device__ void g_huff_codes(const GHuffView& v, uint32_t* cl, uint32_t* first /* 16 */, int lane) {
+    if (lane < 16) first[lane] = 0;
+    wave_sync();
+    for (uint32_t i = lane; i < v.n; i += kWave) {
+        const uint32_t l = v.lengths[i];
+        if (l) atomicAdd(&first[l], 1u);  // counts per length, turned into first codes below
+    }
+    wave_sync();
+    if (lane == 0) {
+        uint32_t code = 0;
+        for (uint32_t len = 1; len <= 15; len++) {
+            const uint32_t c = first[len];
+            first[len] = code;
+            code = (code + c) << 1;
+        }
+    }
+    wave_sync();
+    for (uint32_t base = 0; base < v.n; base += kWave) {
+        const uint32_t i = base + lane;
+        const uint32_t l = i < v.n ? v.lengths[i] : 0;
+        uint32_t rank = 0, same = 0;
+        for (uint32_t len = 1; len <= 15; len++) {
+            const uint64_t m = __ballot(l == len);
+            if (l == len) {
+                rank = (uint32_t)__popcll(m & lanemask_lt(lane));
+                same = (uint32_t)__popcll(m);
+            }
+        }
+        uint32_t code = 0;
+        if (l) code = first[l] + rank;
+        wave_sync();
+        if (l && rank == 0) first[l] += same;  // one lane per length moves its counter on
+        wave_sync();
+        if (i < v.n) cl[i] = l ? ((__brev(code) >> (32 - l)) | (l << 16)) : 0u;
+    }
+}
+
+struct GWriteArgs {
     const uint8_t* in;
     const uint64_t* in_off;
     uint8_t* out;
     const uint64_t* out_off;
     uint32_t* out_len;
     uint64_t n;
-    GStreamWork* stream_work;  // one per resident lane
-    GWaveWork* wave_work;      // one per resident wavefront
+    const GMatchRec* matches;
+    const GBlockRec* blocks;
+    const uint32_t* nblocks;
 };
 
-// Adler-32 of a buffer, one lane (RFC 1950; the reference's simd_adler32 call site compress/mod.rs:137-139)
-__device__ uint32_t g_adler32(const uint8_t* p, uint64_t n) {
-    uint32_t a = 1, b = 0;
-    while (n) {
-        uint32_t k = n > 5552 ? 5552u : (uint32_t)n;
-        n -= k;
-        for (; k; k--) {
-            a += *p++;
-            b += a;
-        }
-        a %= kAdlerMod;
-        b %= kAdlerMod;
-    }
-    return (b << 16) | a;
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
+    uint32_t x = v;
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false));  // row_shr:1
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast:31
+    return x;
 }
 
-// One stream per lane; resident lanes walk the batch with a grid stride.
-template <bool RLE>
-__global__ __launch_bounds__(kWave) void deflate_general_kernel(DeflateGeneralArgs a) {
-    const int lane = threadIdx.x;
-    GStreamWork* sw = a.stream_work + ((uint64_t)blockIdx.x * kWave + lane);
-    GWaveWork* ww = a.wave_work + blockIdx.x;
-    for (uint64_t sid0 = (uint64_t)blockIdx.x * kWave; sid0 < a.n; sid0 += (uint64_t)gridDim.x * kWave) {
-        if (!RLE) {
-            // HashTableMatchFinder::new (hashtable.rs:10-14): all 64 tables of the wavefront are
-            // cleared by the whole wavefront (coalesced 16-B stores), not lane by lane
-            for (int s = 0; s < kWave; s++) {
-                uint4* t = reinterpret_cast<uint4*>(a.stream_work[(uint64_t)blockIdx.x * kWave + s].hash);
-                for (uint32_t i = lane; i < kGHashSize / 4; i += kWave) t[i] = make_uint4(0, 0, 0, 0);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+// One walk over the positions [b0, b1) of a block whose back-references are recs[m0, m1).
+// EMIT = false: symbol frequencies (bitstream.rs:42-66); EMIT = true: the symbols (:121-186).
+template <bool EMIT>
+__device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMatchRec* recs, uint32_t b0, uint32_t b1,
+                       uint32_t m0, uint32_t m1, uint64_t len, uint64_t& acc_a, uint64_t& acc_b) {
+    const uint32_t lane = (uint32_t)br.lane;
+    for (uint32_t i = lane; i < kGChunk; i += kWave) lds.marks[i] = 0;  // (shared with the Huffman scratch)
+    wave_sync();
+    uint32_t mc = m0, covered = b0;  // next record to mark; end of the last back-reference so far
+    uint32_t byte_next = b0 + lane < b1 ? in[b0 + lane] : 0u;
+    for (uint32_t c0 = b0; c0 < b1; c0 += kGChunk) {
+        const uint32_t cend = min(c0 + kGChunk, b1);
+        for (;;) {
+            const uint32_t idx = mc + lane;
+            GMatchRec r{0xFFFFFFFFu, 0};
+            if (idx < m1) r = recs[idx];
+            const bool here = r.start < cend;
+            if (here) lds.marks[r.start - c0] = r.info;
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(here));
+            mc += cnt;
+            if (cnt < (uint32_t)kWave) break;
         }
-        const uint64_t sid = sid0 + lane;
-        if (sid >= a.n) continue;
-        const uint8_t* input = a.in + a.in_off[sid];
-        const uint64_t len = a.in_off[sid + 1] - a.in_off[sid];
-        if (len > (1ull << 30)) {  // write_data splits above 1 GiB (compress/mod.rs:130-136): not supported
-            a.out_len[sid] = 0xFFFFFFFFu;
+        wave_sync();
+        for (uint32_t q = c0; q < cend; q += kWave) {
+            const uint32_t p = q + lane;
+            const bool act = p < cend;
+            const uint32_t byte = byte_next;
+            byte_next = p + kWave < b1 ? in[p + kWave] : 0u;
+            uint32_t mk = 0;
+            if (act) mk = lds.marks[p - c0];
+            if (mk) lds.marks[p - c0] = 0;
+            const uint32_t length = mk & 0x1FF;
+            const uint32_t ends = wave_incl_max_u32(mk ? p + length : 0u);
+            const bool lit = act && !mk && p >= max(covered, ends);
+            covered = max(covered, (uint32_t)__builtin_amdgcn_readlane((int)ends, kWave - 1));
+            uint32_t sym = 0, extra = 0;
+            const uint32_t ds = (mk >> 9) & 31;
+            if (mk) g_length_symbol(length, sym, extra);
+            if (!EMIT) {
+                if (lit) atomicAdd(&lds.freq[byte], 1u);
+                if (mk) {
+                    atomicAdd(&lds.freq[sym], 1u);
+                    atomicAdd(&lds.dfreq[ds], 1u);
+                }
+            } else {
+                if (act) {  // Adler-32 partial sums: A = 1 + sum d_i, B = len + sum (len - i) d_i
+                    acc_a += byte;
+                    acc_b += (len - p) * byte;
+                }
+                uint64_t v = 0;
+                uint32_t nb = 0;
+                if (lit) {
+                    const uint32_t e = lds.cl[byte];
+                    v = e & 0xFFFF;
+                    nb = e >> 16;
+                }
+                if (mk) {  // :163-185 length code, length extra bits, distance code, distance extra bits
+                    const uint32_t e = lds.cl[sym], d = lds.dcl[ds], dm = lds.dmeta[ds];
+                    const uint32_t distance = ((mk >> 14) & 0x7FFF) + 1;
+                    v = e & 0xFFFF;
+                    nb = e >> 16;
+                    v |= (uint64_t)((length - 3) & ((1u << extra) - 1)) << nb;
+                    nb += extra;
+                    v |= (uint64_t)(d & 0xFFFF) << nb;
+                    nb += d >> 16;
+                    v |= (uint64_t)(distance - (dm & 0xFFFF)) << nb;
+                    nb += dm >> 16;
+                }
+                uint32_t total;
+                const uint32_t off = wave_excl_scan_u32(nb, (int)lane, total);
+                if ((uint64_t)total + (br.qbits - br.qflushed) > kEncTileBudget) br.flush(false);
+                br.or_bits128(br.qbits + off, v, 0);
+                br.qbits += total;
+                if (br.qbits - br.qflushed > kEncRingBits / 2) br.flush(false);
+            }
+        }
+    }
+    wave_sync();
+}
+
+__global__ __launch_bounds__(kWave) void deflate_write_kernel(GWriteArgs a) {
+    __shared__ GWriteLds lds;
+    const int lane = threadIdx.x;
+    const uint64_t sid = blockIdx.x;
+    const uint64_t in0 = a.in_off[0], off = a.in_off[sid];
+    const uint8_t* in = a.in + off;
+    const uint64_t len = a.in_off[sid + 1] - off;
+    const uint32_t nblocks = a.nblocks[sid];
+    if (nblocks == 0xFFFFFFFFu) {
+        if (lane == 0) a.out_len[sid] = 0xFFFFFFFFu;
+        return;
+    }
+    const GMatchRec* recs = a.matches + g_match_slice(off - in0, sid);
+    const GBlockRec* blks = a.blocks + g_block_slice(off - in0, sid);
+    for (int i = lane; i < kEncRingDw; i += kWave) lds.ring[i] = 0;
+    if (lane < 30) lds.dmeta[lane] = (uint32_t)kDistBase[lane] | ((uint32_t)kDistExtra[lane] << 16);
+    wave_sync();
+
+    uint8_t* out = a.out + a.out_off[sid];
+    const uint64_t cap = a.out_off[sid + 1] - a.out_off[sid];
+    BitRing br;
+    br.ring = lds.ring;
+    br.lane = lane;
+    br.gmis = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15);
+    br.out_al = out - br.gmis;
+    br.cap_bits = ((uint64_t)br.gmis + cap) * 8;
+    br.qbits = (uint64_t)br.gmis * 8;
+    br.qflushed = 0;
+    br.overflow = false;
+    br.emit_uniform(0x0178, 16);  // zlib header 78 01 (compress/mod.rs:61-63)
+
+    uint64_t acc_a = 0, acc_b = 0;
+    uint32_t b0 = 0, m0 = 0;
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        const uint32_t b1 = uni(blks[blk].end_pos), m1 = uni(blks[blk].match_end), flags = uni(blks[blk].flags);
+        if (flags & kGBlockEmptyFixed) {  // compress/mod.rs:234-238: BFINAL, fixed codes, end of block; flush
+            br.emit_uniform(3, 10);
             continue;
         }
-        GBitWriter bw{0, 0, a.out + a.out_off[sid], a.out_off[sid + 1] - a.out_off[sid], 0, false};
-        const uint8_t hdr[2] = {0x78, 0x01};
-        bw.raw(hdr, 2);
-        GParser ps;
-        ps.sw = sw;
-        ps.ww = ww;
-        ps.lane = lane;
-        ps.nsym = 0;
-        ps.ip = ps.last_match = ps.last_block_end = 0;
-        ps.last_index = 0;
-        ps.m = GMatch{0, 0, 0};
-        const uint64_t window = RLE ? 1 : 32768;
-        // Compressor::write_data (compress/mod.rs:126-159, no buffered input) ...
-        const uint64_t written = ps.compress<RLE>(bw, input, len, 0, 0, false);
-        const uint64_t start = written > window ? written - window : 0;
-        // ... and Compressor::finish (:194-214) over the kept tail input.data = data[start..]
-        ps.compress<RLE>(bw, input + start, len - start, (uint32_t)start, written - start, true);
-        bw.flush();
-        const uint32_t ad = g_adler32(input, len);
-        const uint8_t tr[4] = {(uint8_t)(ad >> 24), (uint8_t)(ad >> 16), (uint8_t)(ad >> 8), (uint8_t)ad};
-        bw.raw(tr, 4);
-        a.out_len[sid] = bw.overflow ? 0xFFFFFFFFu : (uint32_t)bw.pos;
+        // ---- frequencies (bitstream.rs:42-66) ----
+        for (int i = lane; i < 288; i += kWave) lds.freq[i] = i == 256 ? 1u : 0u;
+        if (lane < 32) lds.dfreq[lane] = 0;
+        if (lane < 20) lds.clfreq[lane] = 0;
+        wave_sync();
+        g_walk<false>(lds, br, in, recs, b0, b1, m0, m1, len, acc_a, acc_b);
+        // ---- the two code tables (:68-73) ----
+        const GHuffView vl = g_view(lds.h.big, lds.freq, 286, 15), vd = g_view(lds.h.small, lds.dfreq, 30, 15);
+        g_huff_prepare(vl, lane);
+        g_huff_prepare(vd, lane);
+        wave_sync();
+        if (lane < 2) g_huff_serial(lane == 0 ? vl : vd);
+        wave_sync();
+        g_huff_codes(vl, lds.cl, lds.h.big.first, lane);
+        g_huff_codes(vd, lds.dcl, lds.h.small.first, lane);
+        wave_sync();
+        // ---- header (:75-119): counts trimmed of trailing zero lengths, the code-length code ----
+        uint32_t num_litlen = 286, num_dist = 30;
+        if (lane == 0) {
+            while (num_litlen > 257 && lds.h.big.lengths[num_litlen - 1] == 0) num_litlen--;
+            while (num_dist > 1 && lds.h.small.lengths[num_dist - 1] == 0) num_dist--;
+        }
+        num_litlen = uni(num_litlen);
+        num_dist = uni(num_dist);
+        for (uint32_t i = lane; i < num_litlen + num_dist; i += kWave) {
+            const uint32_t l = i < num_litlen ? lds.h.big.lengths[i] : lds.h.small.lengths[i - num_litlen];
+            atomicAdd(&lds.clfreq[l], 1u);
+        }
+        wave_sync();
+        // the lengths of both tables are needed after the scratch is reused: keep them in cl/dcl (>> 16)
+        {
+            // the code-length tree reuses the small scratch: move the distance lengths out first
+            // (they live on in dcl[] >> 16)
+            const GHuffView vc = g_view(lds.h.small, lds.clfreq, 19, 7);
+            g_huff_prepare(vc, lane);
+            wave_sync();
+            if (lane == 0) g_huff_serial(vc);
+            wave_sync();
+            g_huff_codes(vc, lds.clcl, lds.h.small.first, lane);
+            wave_sync();
+        }
+        br.emit_uniform(((flags & kGBlockEof) ? 5u : 4u) | ((num_litlen - 257) << 3) | ((num_dist - 1) << 8) | (15u << 13), 17);
+        if (br.qbits + 57 - br.qflushed > kEncTileBudget) br.flush(false);
+        if (lane < 19) br.or_bits(br.qbits + 3 * (uint32_t)lane, lds.clcl[kClclOrder[lane]] >> 16);
+        br.qbits += 57;
+        for (uint32_t base = 0; base < num_litlen + num_dist; base += kWave) {
+            const uint32_t i = base + lane;
+            uint32_t bits = 0, nb = 0;
+            if (i < num_litlen + num_dist) {
+                const uint32_t l = (i < num_litlen ? lds.cl[i] : lds.dcl[i - num_litlen]) >> 16;
+                const uint32_t e = lds.clcl[l];
+                bits = e & 0xFFFF;
+                nb = e >> 16;
+            }
+            uint32_t total;
+            const uint32_t o = wave_excl_scan_u32(nb, lane, total);
+            if ((uint64_t)total + (br.qbits - br.qflushed) > kEncTileBudget) br.flush(false);
+            br.or_bits(br.qbits + o, bits);
+            br.qbits += total;
+        }
+        wave_sync();
+        // ---- the symbols, end of block (:121-194) ----
+        g_walk<true>(lds, br, in, recs, b0, b1, m0, m1, len, acc_a, acc_b);
+        br.emit_uniform(lds.cl[256] & 0xFFFF, lds.cl[256] >> 16);
+        b0 = b1;
+        m0 = m1;
     }
+    // ---- Compressor::finish (compress/mod.rs:194-214): pad to a byte, Adler-32 big-endian ----
+    br.emit_uniform(0, (uint32_t)(8 - (br.qbits & 7)) & 7);
+    const uint32_t pa = (uint32_t)(acc_a % kAdlerMod), pb = (uint32_t)(acc_b % kAdlerMod);
+    const uint32_t A = (1u + wave_sum_u32(pa)) % kAdlerMod;
+    const uint32_t B = (uint32_t)(((len % kAdlerMod) + wave_sum_u32(pb)) % kAdlerMod);
+    br.emit_uniform(__builtin_bswap32((B << 16) | A), 32);
+    br.flush(true);
+    if (lane == 0) a.out_len[sid] = br.overflow ? 0xFFFFFFFFu : (uint32_t)((br.qbits >> 3) - br.gmis);
 }
 
 }  // namespace fdh
 
-extern "C" size_t fdh_deflate_general_stream_work_bytes(void) { return sizeof(fdh::GStreamWork); }
-extern "C" size_t fdh_deflate_general_wave_work_bytes(void) { return sizeof(fdh::GWaveWork); }
+extern "C" size_t fdh_deflate_general_hash_bytes(void) { return (size_t)fdh::kGHashSize * 4; }
+// record slices for a batch whose inputs span `total_in` bytes: element counts
+extern "C" size_t fdh_deflate_general_match_records(uint64_t total_in, uint64_t n) { return (size_t)fdh::g_match_slice(total_in, n) + 2; }
+extern "C" size_t fdh_deflate_general_block_records(uint64_t total_in, uint64_t n) { return (size_t)fdh::g_block_slice(total_in, n) + 4; }
+extern "C" size_t fdh_deflate_general_match_record_bytes(void) { return sizeof(fdh::GMatchRec); }
+extern "C" size_t fdh_deflate_general_block_record_bytes(void) { return sizeof(fdh::GBlockRec); }
 
 extern "C" int fdh_launch_deflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
-                                          uint32_t* out_len, uint64_t n, int rle, void* stream_work, void* wave_work,
-                                          unsigned waves, hipStream_t stream) {
+                                          uint32_t* out_len, uint64_t n, int rle, void* hash, void* matches, void* blocks,
+                                          uint32_t* nblocks, unsigned waves, unsigned lanes, hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::DeflateGeneralArgs a{in, in_off, out, out_off, out_len, n, static_cast<fdh::GStreamWork*>(stream_work),
-                              static_cast<fdh::GWaveWork*>(wave_work)};
+    fdh::GParseArgs p{in, in_off, n, static_cast<uint32_t*>(hash), static_cast<fdh::GMatchRec*>(matches),
+                      static_cast<fdh::GBlockRec*>(blocks), nblocks, lanes};
     if (rle)
-        hipLaunchKernelGGL(fdh::deflate_general_kernel<true>, dim3(waves), dim3(fdh::kWave), 0, stream, a);
+        hipLaunchKernelGGL(fdh::deflate_parse_kernel<true>, dim3(waves), dim3(fdh::kWave), 0, stream, p);
     else
-        hipLaunchKernelGGL(fdh::deflate_general_kernel<false>, dim3(waves), dim3(fdh::kWave), 0, stream, a);
+        hipLaunchKernelGGL(fdh::deflate_parse_kernel<false>, dim3(waves), dim3(fdh::kWave), 0, stream, p);
+    fdh::GWriteArgs w{in, in_off, out, out_off, out_len, n, static_cast<const fdh::GMatchRec*>(matches),
+                      static_cast<const fdh::GBlockRec*>(blocks), nblocks};
+    hipLaunchKernelGGL(fdh::deflate_write_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, w);
     return (int)hipGetLastError();
 }

@@ -24,16 +24,19 @@ int fdh_launch_deflate_stored(const uint8_t* in, const uint64_t* in_off, uint8_t
 int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                                  uint32_t* out_len, uint64_t n, hipStream_t stream);
 int fdh_launch_deflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
-                               uint32_t* out_len, uint64_t n, int rle, void* stream_work, void* wave_work, unsigned waves,
-                               hipStream_t stream);
+                               uint32_t* out_len, uint64_t n, int rle, void* hash, void* matches, void* blocks,
+                               uint32_t* nblocks, unsigned waves, unsigned lanes, hipStream_t stream);
 int fdh_launch_png_unfilter(const uint8_t* filt, const uint64_t* filt_off, uint8_t* pix, const uint64_t* pix_off,
                             uint32_t* status, const uint32_t* gate, uint64_t n, uint32_t row_bytes, uint32_t bpp,
                             hipStream_t stream);
 int fdh_launch_png_filter(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types, const uint64_t* types_off,
                           uint8_t* filt, const uint64_t* filt_off, uint32_t* status, uint64_t n, uint32_t row_bytes,
                           uint32_t bpp, hipStream_t stream);
-size_t fdh_deflate_general_stream_work_bytes(void);
-size_t fdh_deflate_general_wave_work_bytes(void);
+size_t fdh_deflate_general_hash_bytes(void);
+size_t fdh_deflate_general_match_records(uint64_t total_in, uint64_t n);
+size_t fdh_deflate_general_block_records(uint64_t total_in, uint64_t n);
+size_t fdh_deflate_general_match_record_bytes(void);
+size_t fdh_deflate_general_block_record_bytes(void);
 }
 
 namespace {
@@ -225,11 +228,29 @@ int fdh_inflate_png_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* fi
 namespace {
 std::mutex g_gen_mutex;
 struct GenWork {
-    void* stream_work = nullptr;
-    void* wave_work = nullptr;
-    unsigned waves = 0;
+    void* hash = nullptr;     // one 64 Ki-entry table per resident lane of the parser (level 1)
+    void* matches = nullptr;  // what the parser hands to the block writer, sliced per stream
+    void* blocks = nullptr;
+    void* nblocks = nullptr;
+    size_t hash_bytes = 0, match_bytes = 0, block_bytes = 0, nblock_bytes = 0;
 };
 GenWork g_gen_work[64];
+
+int grow(void** p, size_t* have, size_t want, const char* what) {
+    if (*have >= want) return FDH_SUCCESS;
+    HIP_TRY(hipDeviceSynchronize());  // nobody may still be using the old buffer
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    const size_t sz = want + want / 4;  // some headroom: batches of similar size do not reallocate
+    hipError_t e = hipMalloc(p, sz);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return hip_fail(e, what);
+    }
+    *have = sz;
+    return FDH_SUCCESS;
+}
 }  // namespace
 
 uint64_t fdh_compress_bound(uint64_t len) { return len + len / 2 + 1024; }
@@ -239,35 +260,51 @@ int fdh_deflate_general_batch(const uint8_t* in, const uint64_t* in_off, uint8_t
     if (n == 0) return FDH_SUCCESS;
     if (!in_off || !out_off || !out_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
     if (mode != FDH_MODE_LEVEL1 && mode != FDH_MODE_RLE) return fail(FDH_ERR_INVALID_ARGUMENT, "unknown encoder mode");
+    if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many streams in one call");
     if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(FDH_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    // one stream per lane: enough resident wavefronts to cover the batch, at most two per CU
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    unsigned waves = (unsigned)std::min<uint64_t>((n + 63) / 64, (uint64_t)2 * cus);
+    // the record arrays are sized by the bytes the batch spans
+    uint64_t ends[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&ends[0], in_off, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&ends[1], in_off + n, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (ends[1] < ends[0]) return fail(FDH_ERR_INVALID_ARGUMENT, "in_off is not ascending");
+    const uint64_t total_in = ends[1] - ends[0];
+    // The parser runs one stream per lane and is bound by the latency of dependent loads: with a
+    // small batch it is given fewer lanes per wavefront and more wavefronts (8 per CU if the batch
+    // allows), capped so that the hash tables of the resident lanes stay below 8 GiB.
+    const bool rle = mode == FDH_MODE_RLE;
+    unsigned lanes = 64;
+    const uint64_t want_waves = (uint64_t)cus * 8;
+    while (lanes > 4 && (n + lanes - 1) / lanes < want_waves) lanes /= 2;
+    if (const char* e = std::getenv("FDH_GEN_LANES")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) lanes = (unsigned)v;
+    }
+    const uint64_t max_resident = 32768;
+    const unsigned waves = (unsigned)std::min<uint64_t>((n + lanes - 1) / lanes, std::max<uint64_t>(1, max_resident / lanes));
     std::lock_guard<std::mutex> lock(g_gen_mutex);  // the workspace is shared by the calls on this device
     GenWork& w = g_gen_work[dev];
-    if (w.waves < waves) {
-        HIP_TRY(hipDeviceSynchronize());  // nobody may still be using the old workspace
-        if (w.stream_work) (void)hipFree(w.stream_work);
-        if (w.wave_work) (void)hipFree(w.wave_work);
-        w = GenWork();
-        HIP_TRY(hipMalloc(&w.stream_work, (size_t)waves * 64 * fdh_deflate_general_stream_work_bytes()));
-        hipError_t e = hipMalloc(&w.wave_work, (size_t)waves * fdh_deflate_general_wave_work_bytes());
-        if (e != hipSuccess) {
-            (void)hipFree(w.stream_work);
-            w = GenWork();
-            return hip_fail(e, "hipMalloc(encoder workspace)");
-        }
-        w.waves = waves;
-    }
-    int rc = fdh_launch_deflate_general(in, in_off, out, out_off, out_len, n, mode == FDH_MODE_RLE, w.stream_work, w.wave_work,
-                                        waves, static_cast<hipStream_t>(hip_stream));
+    int rc = FDH_SUCCESS;
+    if (!rle) rc = grow(&w.hash, &w.hash_bytes, (size_t)waves * lanes * fdh_deflate_general_hash_bytes(), "hipMalloc(hash tables)");
+    if (rc == FDH_SUCCESS)
+        rc = grow(&w.matches, &w.match_bytes, fdh_deflate_general_match_records(total_in, n) * fdh_deflate_general_match_record_bytes(),
+                  "hipMalloc(back-reference records)");
+    if (rc == FDH_SUCCESS)
+        rc = grow(&w.blocks, &w.block_bytes, fdh_deflate_general_block_records(total_in, n) * fdh_deflate_general_block_record_bytes(),
+                  "hipMalloc(block records)");
+    if (rc == FDH_SUCCESS) rc = grow(&w.nblocks, &w.nblock_bytes, (size_t)n * 4, "hipMalloc(block counts)");
+    if (rc != FDH_SUCCESS) return rc;
+    rc = fdh_launch_deflate_general(in, in_off, out, out_off, out_len, n, rle, w.hash, w.matches, w.blocks,
+                                    static_cast<uint32_t*>(w.nblocks), waves, lanes, stream);
     if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "general-encoder kernel launch");
     // the workspace is per device, not per stream: calls are serialised by finishing this one
-    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    HIP_TRY(hipStreamSynchronize(stream));
     return FDH_SUCCESS;
 }
 

@@ -48,4 +48,17 @@ for flags in flag_sets:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    from fdeflate_amd import _lib
+    import ctypes as C
+    Lc = _lib.lib()
+    if hasattr(Lc, "fdh_debug_read_gstat"):
+        g = (C.c_ulonglong * 16)()
+        Lc.fdh_debug_read_gstat(g, 1)
+        fd.inflate_batch(comp, c_off, out, r_off, ol, st, ad, flags=flags)
+        torch.cuda.synchronize()
+        Lc.fdh_debug_read_gstat(g, 1)
+        g = [int(x) for x in g]
+        per = lambda v: v / n
+        print("  per stream: tiles %.1f (%.0f bits, %.0f cycles)  spans %.1f (%.0f bits, %.0f cycles: pass1 %.0f check %.0f pass2 %.0f matches %.0f [%d per stream] tail %.0f)  headers %.1f (%.0f cycles)"
+              % (per(g[0]), per(g[1]), per(g[2]), per(g[3]), per(g[4]), per(g[7]), per(g[10]), per(g[11]), per(g[12]), per(g[13]), per(g[15]), per(g[14]), per(g[9]), per(g[8])))
     print("flags %#x: %.2f ms for %d streams = %.1f GB/s decompressed (ok %d, bytes equal %s)" % (flags, ms, n, n * L / ms / 1e6, ok, same))
