@@ -553,10 +553,21 @@ __device__ void g_huff_serial(const GHuffView& v) {
             v.depth[r - N] = (uint8_t)dch;
         }
     }
-    const uint32_t limit = v.limit;
-    if (max_length > limit) {  // :262-305
-        for (int i = 0; i < 16; i++) v.counts[i] = 0;
-        for (uint32_t i = 0; i < N; i++) v.counts[min((uint32_t)v.lengths[i], limit)]++;
+    v.hdr[2] = max_length;
+}
+
+// Whole wavefront: length limiting (:262-305) when the tree came out deeper than `limit`.
+// The reference sorts the symbols by frequency and hands the adjusted counts out from the longest
+// length down; here every lane finds the rank of its symbols among the used ones directly (by
+// frequency, ties in index order = the order of a stable sort; sort_unstable is an insertion sort
+// up to 20 elements and implementation-defined in its tie order beyond that, see the oracle).
+__device__ void g_huff_limit(const GHuffView& v, uint32_t* start /* 16 */, int lane) {
+    const uint32_t N = v.n, limit = v.limit;
+    if (lane < 16) v.counts[lane] = 0;
+    wave_sync();
+    for (uint32_t i = lane; i < N; i += kWave) atomicAdd(&v.counts[min((uint32_t)v.lengths[i], limit)], 1u);
+    wave_sync();
+    if (lane == 0) {
         uint32_t total = 0;
         for (uint32_t i = 1; i <= limit; i++) total += v.counts[i] << (limit - i);
         while (total > (1u << limit)) {
@@ -567,31 +578,29 @@ __device__ void g_huff_serial(const GHuffView& v) {
             v.counts[i + 1] += 2;
             total--;
         }
-        // by frequency, ties in index order (insertion sort = what sort_unstable does up to 20
-        // elements; beyond that the reference's tie order is implementation-defined)
-        for (uint32_t i = 0; i < N; i++) v.order[i] = (uint16_t)i;
-        for (uint32_t i = 1; i < N; i++) {
-            const uint16_t x = v.order[i];
-            const uint32_t fx = v.freq[x];
-            uint32_t j = i;
-            while (j > 0 && v.freq[v.order[j - 1]] > fx) {
-                v.order[j] = v.order[j - 1];
-                j--;
-            }
-            v.order[j] = x;
+        uint32_t at = 0;  // the first counts[limit] used symbols (rarest first) get `limit`, and so on down
+        for (uint32_t len = limit; len >= 1; len--) {
+            start[len] = at;
+            at += v.counts[len];
         }
-        uint32_t len = limit;
-        for (uint32_t k = 0; k < N; k++) {
-            const uint32_t i = v.order[k];
-            if (v.freq[i] > 0) {
-                while (v.counts[len] == 0) len--;
-                v.lengths[i] = (uint8_t)len;
-                v.counts[len]--;
-            }
-        }
-        max_length = limit;
+        v.hdr[2] = limit;
     }
-    v.hdr[2] = max_length;
+    wave_sync();
+    for (uint32_t base = 0; base < N; base += kWave) {
+        const uint32_t i = base + lane;
+        const uint32_t fi = i < N ? v.freq[i] : 0;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < N; j++) {
+            const uint32_t fj = v.freq[j];  // same address in every lane: one broadcast read
+            rank += (fj > 0 && (fj < fi || (fj == fi && j < i))) ? 1u : 0u;
+        }
+        if (fi > 0) {
+            uint32_t len = limit;
+            while (len > 1 && !(rank >= start[len] && rank < start[len] + v.counts[len])) len--;
+            v.lengths[i] = (uint8_t)len;
+        }
+    }
+    wave_sync();
 }
 
 // Whole wavefront: canonical codes, bit-reversed (:308-320), as code | length << 16.
@@ -787,6 +796,8 @@ __global__ __launch_bounds__(kWave) void deflate_write_kernel(GWriteArgs a) {
         wave_sync();
         if (lane < 2) g_huff_serial(lane == 0 ? vl : vd);
         wave_sync();
+        if (uni(lds.h.big.max_length) > 15) g_huff_limit(vl, lds.h.big.first, lane);
+        if (uni(lds.h.small.max_length) > 15) g_huff_limit(vd, lds.h.small.first, lane);
         g_huff_codes(vl, lds.cl, lds.h.big.first, lane);
         g_huff_codes(vd, lds.dcl, lds.h.small.first, lane);
         wave_sync();
@@ -812,6 +823,7 @@ __global__ __launch_bounds__(kWave) void deflate_write_kernel(GWriteArgs a) {
             wave_sync();
             if (lane == 0) g_huff_serial(vc);
             wave_sync();
+            if (uni(lds.h.small.max_length) > 7) g_huff_limit(vc, lds.h.small.first, lane);
             g_huff_codes(vc, lds.clcl, lds.h.small.first, lane);
             wave_sync();
         }

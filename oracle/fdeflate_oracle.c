@@ -1814,6 +1814,11 @@ static HItem heap_pop(HItem *d, size_t *len) {
     return item;
 }
 
+
+/* How often build_huffman_tree had to shorten a tree (bitstream.rs:262-305): [0] limit 15, [1] limit 7.
+ * Test instrumentation only (not thread-safe): lets a test show that its input takes that path. */
+unsigned long fdo_length_limit_events[2];
+
 static int g_build_huffman_tree(const uint32_t *freq, size_t n, uint8_t *lengths, uint16_t *codes,
                                 uint8_t length_limit) {
     size_t used = 0, first = 0;
@@ -1888,6 +1893,7 @@ static int g_build_huffman_tree(const uint32_t *freq, size_t n, uint8_t *lengths
         }
     }
     if (max_length > length_limit) {
+        fdo_length_limit_events[length_limit == 7 ? 1 : 0]++;
         uint32_t counts[16] = {0};
         for (size_t i = 0; i < n; i++) {
             counts[lengths[i] < length_limit ? lengths[i] : length_limit]++;

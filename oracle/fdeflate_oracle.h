@@ -118,6 +118,8 @@ size_t fdo_compress_stored(const uint8_t *input, size_t len, uint8_t *out, size_
 size_t fdo_compress_bound(size_t len);
 size_t fdo_compress_level1(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap);
 size_t fdo_compress_rle(const uint8_t *input, size_t len, uint8_t *out, size_t out_cap);
+/* test instrumentation: trees shortened so far, [0] to 15 bits, [1] to 7 bits */
+extern unsigned long fdo_length_limit_events[2];
 
 /* ---- PNG scanline filters (PNG specification section 9; the png crate's step either side of the
  * codec).  filt = rows x (1 + row_bytes) with the filter-type byte first, pix = rows x row_bytes.

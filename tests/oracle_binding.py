@@ -146,6 +146,12 @@ def compress_level1(data):
     return _compress_general(lib().fdo_compress_level1, data)
 
 
+def length_limit_events():
+    """(trees shortened to 15 bits, to 7 bits) by the general encoder so far -- test instrumentation"""
+    a = (C.c_ulong * 2).in_dll(lib(), "fdo_length_limit_events")
+    return int(a[0]), int(a[1])
+
+
 def compress_rle(data):
     """compress_to_vec_rle (src/compress/mod.rs:306)"""
     return _compress_general(lib().fdo_compress_rle, data)

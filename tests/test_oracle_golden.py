@@ -394,7 +394,46 @@ def _encoder_inputs():
         out.append(synth.gen_stream_np(i, 65536).tobytes())
     out.append(bytes(r.integers(0, 3, 300000, dtype=np.uint8)))      # > 16384 symbols: several blocks
     out.append(bytes(r.integers(0, 256, 70000, dtype=np.uint8)))     # incompressible, skip-ahead path
+    out.extend(_length_limited_inputs())
     return out
+
+
+def _length_limited_inputs():
+    """Inputs whose Huffman trees come out deeper than the format allows, so that
+    build_huffman_tree has to shorten them (bitstream.rs:262-305): [0] the literal/length tree
+    (Fibonacci frequencies, interleaved with other bytes so that nothing repeats into a match),
+    [1] the code-length tree (counts per code length that are Fibonacci-like)."""
+    fib = [1, 1]
+    while len(fib) < 20:
+        fib.append(fib[-1] + fib[-2])
+    r = np.random.default_rng(11)
+    a = np.concatenate([np.full(f, k, dtype=np.uint8) for k, f in enumerate(fib)])
+    r.shuffle(a)
+    both = np.empty(2 * a.size, dtype=np.uint8)
+    both[0::2] = a
+    both[1::2] = r.integers(100, 104, a.size, dtype=np.uint8)
+    parts, sym = [], 0
+    for count, freq in ((34, 256), (21, 128), (13, 64), (8, 32), (5, 16), (3, 8), (2, 4), (1, 2), (1, 1)):
+        for _ in range(count):
+            parts.append(np.full(freq, sym, dtype=np.uint8))
+            sym += 1
+    cl = np.concatenate(parts)
+    np.random.default_rng(5).shuffle(cl)
+    return [both.tobytes(), cl.tobytes()]
+
+
+def test_general_encoder_inputs_reach_the_length_limits():
+    """The inputs above do take the tree-shortening path in the oracle (so the GPU parity test
+    over the same inputs covers it), for the 15-bit and for the 7-bit limit."""
+    deep, cl = _length_limited_inputs()
+    e0 = ob.length_limit_events()
+    for enc in (ob.compress_level1, ob.compress_rle):
+        assert zlib.decompress(enc(deep)) == deep
+    e1 = ob.length_limit_events()
+    for enc in (ob.compress_level1, ob.compress_rle):
+        assert zlib.decompress(enc(cl)) == cl
+    e2 = ob.length_limit_events()
+    assert e1[0] - e0[0] == 2 and e2[1] - e1[1] == 2, (e0, e1, e2)
 
 
 def test_general_encoder_empty_input_kat():
