@@ -82,6 +82,15 @@ __device__ __forceinline__ uint64_t g_load64(const uint8_t* p) {
 }
 __device__ __forceinline__ uint32_t g_hash(uint64_t v) { return (uint32_t)((11400714785074694791ull * v) >> 40) & (kGHashSize - 1); }
 
+#ifdef FDH_DEBUG_GEN
+__device__ uint64_t g_gen_t[8][32768];
+#define GT0(k) const uint64_t _t##k = __builtin_readcyclecounter()
+#define GT1(k) tacc[k] += __builtin_readcyclecounter() - _t##k
+#else
+#define GT0(k)
+#define GT1(k)
+#endif
+
 struct GMatch {
     uint32_t length, distance;
     uint64_t start;
@@ -99,13 +108,53 @@ struct GParser {
     uint64_t ip, last_match, last_block_end;
     uint32_t last_index;
     GMatch m;
+#ifdef FDH_DEBUG_GEN
+    uint64_t tacc[8];
+#endif
 
     // distance_to_dist_sym (bitstream.rs:16-27)
     __device__ static uint32_t dist_sym_of(uint32_t distance) {
         if (distance <= 16) return kGDistLookup[distance - 1];
-        uint32_t s = 29;
-        while (s > 0 && distance < kDistBase[s]) s--;
-        return s;
+        const uint32_t d1 = distance - 1, l = 31 - (uint32_t)__clz(d1);  // two symbols per power of two
+        return 2 * l + ((d1 >> (l - 1)) & 1);
+    }
+
+    // Equal bytes walking backwards, data[a_end - 1 - i] == data[b_end - 1 - i] for i < limit
+    // (limit <= min(a_end, b_end)), eight at a time: the reference's byte loops (matchfinder/mod.rs
+    // :66-72, parse/mod.rs:72-81) give the same count, a dependent byte load per step is what they
+    // would cost here.
+    __device__ static uint32_t back_equal(const uint8_t* data, uint64_t a_end, uint64_t b_end, uint32_t limit) {
+        uint32_t n = 0;
+        while (n + 8 <= limit) {
+            const uint64_t x = g_load64(data + a_end - n - 8) ^ g_load64(data + b_end - n - 8);
+            if (x) return n + ((uint32_t)__builtin_clzll(x) >> 3);
+            n += 8;
+        }
+        if (n < limit) {
+            if (a_end - n >= 8 && b_end - n >= 8) {
+                const uint64_t x = g_load64(data + a_end - n - 8) ^ g_load64(data + b_end - n - 8);
+                return n + min(x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u, limit - n);
+            }
+            while (n < limit && data[a_end - n - 1] == data[b_end - n - 1]) n++;
+        }
+        return n;
+    }
+    // Equal bytes walking forwards, a[i] == b[i] for i < limit; `wide_tail`: 8 bytes may be read at
+    // any offset below limit.
+    __device__ static uint32_t fwd_equal(const uint8_t* a, const uint8_t* b, uint32_t limit, bool wide_tail) {
+        uint32_t k = 0;
+        for (; k + 8 <= limit; k += 8) {
+            const uint64_t x = g_load64(a + k) ^ g_load64(b + k);
+            if (x) return k + ((uint32_t)__builtin_ctzll(x) >> 3);
+        }
+        if (k < limit) {
+            if (wide_tail) {
+                const uint64_t x = g_load64(a + k) ^ g_load64(b + k);
+                return k + min(x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u, limit - k);
+            }
+            while (k < limit && a[k] == b[k]) k++;
+        }
+        return k;
     }
 
     // match_length::<true> (matchfinder/mod.rs:51-111)
@@ -117,32 +166,15 @@ struct GParser {
             return;
         }
         uint64_t length = 8;
-        while (length < 258 && ip > anchor && prev_index > 0 && data[ip - 1] == data[prev_index - 1]) {
-            length++;
-            ip--;
-            prev_index--;
+        {   // backwards while length < 258 && ip > anchor && prev_index > 0 && the bytes in front agree
+            const uint32_t n = back_equal(data, ip, prev_index, (uint32_t)min(min((uint64_t)250, ip - anchor), prev_index));
+            length += n;
+            ip -= n;
+            prev_index -= n;
         }
         uint64_t slice = len - ip - length;
         if (slice > 258 - length) slice = 258 - length;
-        const uint8_t *a = data + ip + length, *b = data + prev_index + length;
-        uint64_t k = 0;
-        bool done = false;
-        for (; k + 8 <= slice; k += 8) {
-            const uint64_t x = g_load64(a + k), y = g_load64(b + k);
-            if (x == y) {
-                length += 8;
-            } else {
-                length += (uint64_t)__builtin_ctzll(x ^ y) / 8;
-                done = true;
-                break;
-            }
-        }
-        if (!done) {
-            for (; k < slice; k++) {
-                if (a[k] != b[k]) break;
-                length++;
-            }
-        }
+        length += fwd_equal(data + ip + length, data + prev_index + length, (uint32_t)slice, ip + length + slice + 8 <= len);
         out_len = (uint32_t)length;
         out_start = ip;
     }
@@ -154,15 +186,47 @@ struct GParser {
         uint64_t min_start = max((uint64_t)1, last_match);
         const uint64_t e = r.end();
         if (e > 258) min_start = max(min_start, e - 258);
-        while (r.start > min_start && data[r.start - 2] == value) {
-            r.start--;
-            r.length++;
+        const uint64_t v8 = 0x0101010101010101ull * value;
+        {   // while r.start > min_start && data[r.start - 2] == value: one byte further back
+            const uint32_t limit = r.start > min_start ? (uint32_t)(r.start - min_start) : 0u;
+            const uint64_t end = r.start - 1;  // the bytes tested are data[end - 1], data[end - 2], ...
+            uint32_t n = 0;
+            bool stop = false;
+            while (!stop && n + 8 <= limit) {
+                const uint64_t x = g_load64(data + end - n - 8) ^ v8;
+                if (x) {
+                    n += (uint32_t)__builtin_clzll(x) >> 3;
+                    stop = true;
+                } else {
+                    n += 8;
+                }
+            }
+            if (!stop && n < limit) {
+                if (end - n >= 8) {
+                    const uint64_t x = g_load64(data + end - n - 8) ^ v8;
+                    n += min(x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u, limit - n);
+                } else {
+                    while (n < limit && data[end - n - 1] == value) n++;
+                }
+            }
+            r.start -= n;
+            r.length += n;
         }
-        const uint8_t* p = data + r.end();
         uint64_t n = len - r.end();
         if (n > 258 - r.length) n = 258 - r.length;
-        const uint64_t v8 = 0x0101010101010101ull * value;
+        const uint8_t* p = data + r.end();
         uint64_t k = 0;
+        for (; k + 32 <= n; k += 32) {  // four loads in flight
+            const uint64_t c0 = g_load64(p + k) ^ v8, c1 = g_load64(p + k + 8) ^ v8, c2 = g_load64(p + k + 16) ^ v8, c3 = g_load64(p + k + 24) ^ v8;
+            if (c0 | c1 | c2 | c3) {
+                const uint32_t m = c0 ? (uint32_t)__builtin_ctzll(c0) >> 3
+                                   : c1 ? 8 + ((uint32_t)__builtin_ctzll(c1) >> 3)
+                                   : c2 ? 16 + ((uint32_t)__builtin_ctzll(c2) >> 3) : 24 + ((uint32_t)__builtin_ctzll(c3) >> 3);
+                r.length += m;
+                return r;
+            }
+            r.length += 32;
+        }
         for (; k + 8 <= n; k += 8) {
             const uint64_t c = g_load64(p + k);
             if (c != v8) {
@@ -171,9 +235,16 @@ struct GParser {
             }
             r.length += 8;
         }
-        for (; k < n; k++) {
-            if (p[k] != value) break;
-            r.length++;
+        if (k < n) {
+            if (r.end() + 8 <= len) {  // (r.end() has moved with r.length: the next 8 bytes are inside the buffer)
+                const uint64_t x = g_load64(data + r.end()) ^ v8;
+                r.length += min(x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u, (uint32_t)(n - k));
+            } else {
+                for (; k < n; k++) {
+                    if (p[k] != value) break;
+                    r.length++;
+                }
+            }
         }
         return r;
     }
@@ -202,33 +273,101 @@ struct GParser {
                 match_length8(current, data, len, anchor, ip, (uint64_t)(offset - base_index), l, st);
                 if (l >= 8) r = GMatch{l, (uint32_t)(ip - (uint64_t)(offset - base_index)), st};
             }
-            if (fizzle) {
-                while (r.length < 258 && r.start > last_match && r.start > (uint64_t)r.distance + 1 &&
-                       data[r.start - 1] == data[r.start - r.distance - 1]) {
-                    r.length++;
-                    r.start--;
-                }
+            if (fizzle && r.length != 0) {  // parse/mod.rs:72-81: take bytes in front of the match while they agree
+                const uint64_t room = r.start > (uint64_t)r.distance + 1 ? r.start - r.distance - 1 : 0;  // (never down to byte 0)
+                const uint64_t lim = min(min((uint64_t)(258 - r.length), r.start - last_match), room);
+                const uint32_t n = back_equal(data, r.start, r.start - r.distance, (uint32_t)lim);
+                r.length += n;
+                r.start -= n;
             }
         }
         ip++;
         return r;
     }
 
+    // ParserInner::advance_to_match (parse/mod.rs:88-102).  A step that finds nothing costs two
+    // dependent memory round trips (the 8 bytes at ip, then the table entry they hash to) and where
+    // the next step looks does not depend on either, so the steps are taken kGroup at a time along
+    // the path the scan follows while it finds nothing: all the data loads, then all the table loads,
+    // then the decisions one by one in order.  The loads of a group are issued before its stores, so
+    // an entry that an earlier step of the same group would have replaced is patched from registers;
+    // the steps behind a hit are dropped without having stored anything.
+    static constexpr int kGroup = 8;
     template <bool RLE>
     __device__ GMatch advance_to_match(const uint8_t* data, uint64_t len, uint32_t base_index, uint64_t max_ip) {
         while (ip < max_ip) {
-            const GMatch r = get_match<RLE>(data, len, base_index, false);
-            if (r.length != 0) return r;
-            ip += (ip - last_match) >> 5;  // skip_ahead_shift = 5 (compress/mod.rs:76, :114)
+            uint64_t p[kGroup], cur[kGroup];
+            uint32_t h[kGroup], off[kGroup];
+            uint64_t q = ip;
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                p[k] = q;
+                cur[k] = g_load64(data + (q < max_ip ? q : ip));
+                q++;
+                q += (q - last_match) >> 5;  // skip_ahead_shift = 5 (compress/mod.rs:76, :114)
+            }
+            if (!RLE) {
+#pragma unroll
+                for (int k = 0; k < kGroup; k++) {
+                    h[k] = g_hash(cur[k]);
+                    off[k] = hash[h[k]];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                ip = p[k];
+                if (ip >= max_ip) return GMatch{0, 0, 0};
+                // ParserInner::get_match (parse/mod.rs:58-85), fizzle = false
+                const uint64_t current = cur[k];
+                if ((uint32_t)current == (uint32_t)(current >> 8)) {
+                    GT0(1);
+                    const GMatch r = rle_match(data, len);
+                    GT1(1);
+                    ip = r.end() - 3;
+                    return r;
+                }
+                if (!RLE) {  // HashTableMatchFinder::get_and_insert (hashtable.rs:16-50)
+                    uint32_t offset = off[k];
+#pragma unroll
+                    for (int j = 0; j < k; j++)
+                        if (h[j] == h[k]) offset = (uint32_t)p[j] + base_index;
+                    hash[h[k]] = (uint32_t)ip + base_index;
+                    const uint32_t sub = (uint32_t)ip > 32768 ? (uint32_t)ip - 32768 : 0;
+                    const uint32_t min_offset = max(base_index + sub, 1u);
+                    if (offset >= min_offset) {
+                        uint32_t l;
+                        uint64_t st;
+                        GT0(2);
+                        match_length8(current, data, len, last_match, ip, (uint64_t)(offset - base_index), l, st);
+                        GT1(2);
+                        if (l >= 8) {
+                            const GMatch r{l, (uint32_t)(ip - (uint64_t)(offset - base_index)), st};
+                            ip++;
+                            return r;
+                        }
+                    }
+                }
+            }
+            ip = q;
         }
         return GMatch{0, 0, 0};
     }
 
+    // ParserInner::advance (parse/mod.rs:105-114): the positions covered by a match go into the
+    // table; four at a time (the loads are independent, the stores stay in position order)
     template <bool RLE>
     __device__ void advance(const uint8_t* data, uint64_t len, uint32_t base_index, uint64_t end) {
         if (!RLE) {
             const uint64_t stop = min(end, len - 8);
-            for (uint64_t j = ip; j < stop; j++) hash[g_hash(g_load64(data + j))] = base_index + (uint32_t)j;
+            uint64_t j = ip;
+            for (; j + 4 <= stop; j += 4) {
+                const uint64_t v0 = g_load64(data + j), v1 = g_load64(data + j + 1), v2 = g_load64(data + j + 2), v3 = g_load64(data + j + 3);
+                hash[g_hash(v0)] = base_index + (uint32_t)j;
+                hash[g_hash(v1)] = base_index + (uint32_t)j + 1;
+                hash[g_hash(v2)] = base_index + (uint32_t)j + 2;
+                hash[g_hash(v3)] = base_index + (uint32_t)j + 3;
+            }
+            for (; j < stop; j++) hash[g_hash(g_load64(data + j))] = base_index + (uint32_t)j;
         }
         ip = max(ip, end);
     }
@@ -302,13 +441,19 @@ struct GParser {
         } else {
             for (;;) {
                 if (m.length == 0) {
+                    GT0(0);
                     m = advance_to_match<false>(data, len, base_index, max_ip);
+                    GT1(0);
                     if (m.length == 0) break;
                 }
+                GT0(3);
                 advance<false>(data, len, base_index, m.end());
+                GT1(3);
                 GMatch m2{0, 0, 0};
                 if (ip < max_ip) {
+                    GT0(4);
                     m2 = get_match<false>(data, len, base_index, true);
+                    GT1(4);
                 } else if (!finish) {
                     break;
                 }
@@ -371,6 +516,10 @@ __global__ __launch_bounds__(kWave) void deflate_parse_kernel(GParseArgs a) {
         ps.ip = ps.last_match = ps.last_block_end = 0;
         ps.last_index = 0;
         ps.m = GMatch{0, 0, 0};
+#ifdef FDH_DEBUG_GEN
+        for (int k = 0; k < 8; k++) ps.tacc[k] = 0;
+        const uint64_t t_all = __builtin_readcyclecounter();
+#endif
         const uint64_t window = RLE ? 1 : 32768;
         // Compressor::write_data (compress/mod.rs:126-159, no buffered input) ...
         const uint64_t written = ps.compress<RLE>(input, len, 0, 0, false);
@@ -378,6 +527,12 @@ __global__ __launch_bounds__(kWave) void deflate_parse_kernel(GParseArgs a) {
         // ... and Compressor::finish (:194-214) over the kept tail input.data = data[start..]
         ps.compress<RLE>(input + start, len - start, (uint32_t)start, written - start, true);
         a.nblocks[sid] = ps.nblock;
+#ifdef FDH_DEBUG_GEN
+        if (sid < 32768) {
+            ps.tacc[7] = __builtin_readcyclecounter() - t_all;
+            for (int k = 0; k < 8; k++) g_gen_t[k][sid] = ps.tacc[k];
+        }
+#endif
     }
 }
 
@@ -864,6 +1019,12 @@ __global__ __launch_bounds__(kWave) void deflate_write_kernel(GWriteArgs a) {
 }
 
 }  // namespace fdh
+
+#ifdef FDH_DEBUG_GEN
+extern "C" int fdh_debug_gen_timers(uint64_t* host /* 8 x 32768 */) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_gen_t), sizeof(uint64_t) * 8 * 32768);
+}
+#endif
 
 extern "C" size_t fdh_deflate_general_hash_bytes(void) { return (size_t)fdh::kGHashSize * 4; }
 // record slices for a batch whose inputs span `total_in` bytes: element counts
