@@ -9,11 +9,14 @@
 
 namespace fdh {
 
-constexpr int kEncRingDw = 2048;         // 8 KiB bit ring per wavefront
-constexpr uint32_t kEncRingBits = kEncRingDw * 32;
-constexpr uint32_t kEncTileBudget = kEncRingBits - 1024;
+// RING_DW dwords of LDS per wavefront (a power of two); a wavefront-wide update may add up to
+// kTileBudget bits to what has not been flushed yet.
+template <int RING_DW>
+struct BitRingT {
+    static constexpr int kEncRingDw = RING_DW;
+    static constexpr uint32_t kEncRingBits = RING_DW * 32;
+    static constexpr uint32_t kEncTileBudget = kEncRingBits - 1024;
 
-struct BitRing {
     uint32_t* ring;
     int lane;
     uint8_t* out_al;   // slot base rounded down to 16 B

@@ -539,6 +539,9 @@ __global__ __launch_bounds__(kWave) void deflate_parse_kernel(GParseArgs a) {
 // ============================ kernel 2: the block writer, one stream per wavefront ============================
 
 constexpr uint32_t kGChunk = 1024;  // positions per refill of the marks
+constexpr int kGRingDw = 512;       // 2 KiB bit ring: a step of the walk adds at most 64 x 118 bits
+using BitRing = BitRingT<kGRingDw>;
+constexpr uint32_t kEncTileBudget = BitRing::kEncTileBudget, kEncRingBits = BitRing::kEncRingBits;
 
 // Scratch of one Huffman construction (build_huffman_tree, bitstream.rs:198-325).
 template <int CAP>
@@ -547,7 +550,6 @@ struct GHuffScratch {
     uint16_t in_left[CAP], in_right[CAP];
     uint8_t depth[CAP];        // of the internal nodes
     uint8_t lengths[CAP];
-    uint16_t order[CAP];
     uint32_t counts[16], first[16];
     uint32_t heap_len, used, max_length, pad;
 };
@@ -555,7 +557,7 @@ struct GHuffScratch {
 struct GHuffView {  // the same code runs on two lanes over different trees
     uint32_t* freq;
     uint64_t* heap;
-    uint16_t *in_left, *in_right, *order;
+    uint16_t *in_left, *in_right;
     uint8_t *depth, *lengths;
     uint32_t *counts, *hdr;  // hdr[0] heap_len, [1] used, [2] max_length
     uint32_t n, limit;
@@ -563,16 +565,16 @@ struct GHuffView {  // the same code runs on two lanes over different trees
 
 template <int CAP>
 __device__ __forceinline__ GHuffView g_view(GHuffScratch<CAP>& s, uint32_t* freq, uint32_t n, uint32_t limit) {
-    return GHuffView{freq, s.heap, s.in_left, s.in_right, s.order, s.depth, s.lengths, s.counts, &s.heap_len, n, limit};
+    return GHuffView{freq, s.heap, s.in_left, s.in_right, s.depth, s.lengths, s.counts, &s.heap_len, n, limit};
 }
 
 struct GWriteLds {
-    uint32_t ring[kEncRingDw];
+    uint32_t ring[kGRingDw];
     uint32_t freq[288], dfreq[32], clfreq[20];
     uint32_t cl[288], dcl[32], clcl[20];  // code | length << 16
     uint32_t dmeta[32];                   // distance base | extra bits << 16
     union {
-        uint32_t marks[kGChunk];  // info of the back-reference that starts at a position of the chunk, else 0
+        alignas(16) uint32_t marks[kGChunk];  // info of the back-reference that starts at a position of the chunk, else 0
         struct {
             GHuffScratch<288> big;
             GHuffScratch<32> small;
@@ -819,16 +821,43 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
     return x;
 }
 
+// Appends `n` bits (n <= 48) to the value {v1:v0} that holds `nb` bits (nb + n <= 128).
+__device__ __forceinline__ void g_append(uint64_t& v0, uint64_t& v1, uint32_t& nb, uint64_t bits, uint32_t n) {
+    if (nb < 64) {
+        v0 |= bits << nb;
+        if (nb + n > 64) v1 |= bits >> (64 - nb);
+    } else {
+        v1 |= bits << (nb - 64);
+    }
+    nb += n;
+}
+
 // One walk over the positions [b0, b1) of a block whose back-references are recs[m0, m1).
 // EMIT = false: symbol frequencies (bitstream.rs:42-66); EMIT = true: the symbols (:121-186).
+// Every lane takes four consecutive positions per step (256 per wavefront): back-references are at
+// least four bytes long, so a lane sees at most one or two of them and its codes stay below the
+// 118 bits one ring update takes.
 template <bool EMIT>
 __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMatchRec* recs, uint32_t b0, uint32_t b1,
                        uint32_t m0, uint32_t m1, uint64_t len, uint64_t& acc_a, uint64_t& acc_b) {
     const uint32_t lane = (uint32_t)br.lane;
+    constexpr uint32_t kStep = 4 * kWave;
     for (uint32_t i = lane; i < kGChunk; i += kWave) lds.marks[i] = 0;  // (shared with the Huffman scratch)
     wave_sync();
+    // the four bytes at p, read as one dword where the stream has them (never past its end)
+    auto load4 = [&](uint32_t p) -> uint32_t {
+        if (p >= b1) return 0u;
+        if ((uint64_t)p + 4 <= len) {
+            uint32_t w;
+            __builtin_memcpy(&w, in + p, 4);
+            return w;
+        }
+        uint32_t w = 0;
+        for (uint32_t j = 0; (uint64_t)p + j < len; j++) w |= (uint32_t)in[p + j] << (8 * j);
+        return w;
+    };
     uint32_t mc = m0, covered = b0;  // next record to mark; end of the last back-reference so far
-    uint32_t byte_next = b0 + lane < b1 ? in[b0 + lane] : 0u;
+    uint32_t word_next = load4(b0 + 4 * lane);
     for (uint32_t c0 = b0; c0 < b1; c0 += kGChunk) {
         const uint32_t cend = min(c0 + kGChunk, b1);
         for (;;) {
@@ -842,55 +871,68 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
             if (cnt < (uint32_t)kWave) break;
         }
         wave_sync();
-        for (uint32_t q = c0; q < cend; q += kWave) {
-            const uint32_t p = q + lane;
-            const bool act = p < cend;
-            const uint32_t byte = byte_next;
-            byte_next = p + kWave < b1 ? in[p + kWave] : 0u;
-            uint32_t mk = 0;
-            if (act) mk = lds.marks[p - c0];
-            if (mk) lds.marks[p - c0] = 0;
-            const uint32_t length = mk & 0x1FF;
-            const uint32_t ends = wave_incl_max_u32(mk ? p + length : 0u);
-            const bool lit = act && !mk && p >= max(covered, ends);
-            covered = max(covered, (uint32_t)__builtin_amdgcn_readlane((int)ends, kWave - 1));
-            uint32_t sym = 0, extra = 0;
-            const uint32_t ds = (mk >> 9) & 31;
-            if (mk) g_length_symbol(length, sym, extra);
-            if (!EMIT) {
-                if (lit) atomicAdd(&lds.freq[byte], 1u);
-                if (mk) {
-                    atomicAdd(&lds.freq[sym], 1u);
-                    atomicAdd(&lds.dfreq[ds], 1u);
+        for (uint32_t q = c0; q < cend; q += kStep) {
+            const uint32_t p0 = q + 4 * lane;
+            const uint32_t nact = p0 < cend ? min(cend - p0, 4u) : 0u;
+            uint32_t word = word_next;
+            word_next = load4(p0 + kStep);
+            if (nact < 4) word &= nact ? (1u << (8 * nact)) - 1 : 0u;  // (the bytes behind belong to the next block)
+            uint4 mk4 = *reinterpret_cast<const uint4*>(&lds.marks[p0 - c0]);
+            if (mk4.x | mk4.y | mk4.z | mk4.w) *reinterpret_cast<uint4*>(&lds.marks[p0 - c0]) = make_uint4(0, 0, 0, 0);
+            const uint32_t mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
+            uint32_t e = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (mk[j]) e = p0 + j + (mk[j] & 0x1FF);
+            const uint32_t incl = wave_incl_max_u32(e);
+            const uint32_t before = (uint32_t)__shfl_up((int)incl, 1, kWave);
+            uint32_t cov = max(covered, lane ? before : 0u);  // end of the last back-reference in front of p0
+            covered = max(covered, (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1));
+            if (EMIT) {  // Adler-32 partial sums: A = 1 + sum d_i, B = len + sum (len - i) d_i
+                const uint32_t sum = bytesum4(word);
+                acc_a += sum;
+                acc_b += (len - p0) * sum - bytedot4(word, 0x03020100u, 0);
+            }
+            uint64_t v0 = 0, v1 = 0;
+            uint32_t nb = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = p0 + j, byte = (word >> (8 * j)) & 0xFF;
+                if (mk[j]) {
+                    const uint32_t length = mk[j] & 0x1FF, ds = (mk[j] >> 9) & 31;
+                    uint32_t sym, extra;
+                    g_length_symbol(length, sym, extra);
+                    cov = p + length;
+                    if (!EMIT) {
+                        atomicAdd(&lds.freq[sym], 1u);
+                        atomicAdd(&lds.dfreq[ds], 1u);
+                    } else {  // :163-185 length code, length extra bits, distance code, distance extra bits
+                        const uint32_t el = lds.cl[sym], d = lds.dcl[ds], dm = lds.dmeta[ds];
+                        const uint32_t distance = ((mk[j] >> 14) & 0x7FFF) + 1;
+                        uint64_t v = el & 0xFFFF;
+                        uint32_t n = el >> 16;
+                        v |= (uint64_t)((length - 3) & ((1u << extra) - 1)) << n;
+                        n += extra;
+                        v |= (uint64_t)(d & 0xFFFF) << n;
+                        n += d >> 16;
+                        v |= (uint64_t)(distance - (dm & 0xFFFF)) << n;
+                        n += dm >> 16;
+                        g_append(v0, v1, nb, v, n);
+                    }
+                } else if ((uint32_t)j < nact && p >= cov) {  // a literal
+                    if (!EMIT) {
+                        atomicAdd(&lds.freq[byte], 1u);
+                    } else {
+                        const uint32_t el = lds.cl[byte];
+                        g_append(v0, v1, nb, el & 0xFFFF, el >> 16);
+                    }
                 }
-            } else {
-                if (act) {  // Adler-32 partial sums: A = 1 + sum d_i, B = len + sum (len - i) d_i
-                    acc_a += byte;
-                    acc_b += (len - p) * byte;
-                }
-                uint64_t v = 0;
-                uint32_t nb = 0;
-                if (lit) {
-                    const uint32_t e = lds.cl[byte];
-                    v = e & 0xFFFF;
-                    nb = e >> 16;
-                }
-                if (mk) {  // :163-185 length code, length extra bits, distance code, distance extra bits
-                    const uint32_t e = lds.cl[sym], d = lds.dcl[ds], dm = lds.dmeta[ds];
-                    const uint32_t distance = ((mk >> 14) & 0x7FFF) + 1;
-                    v = e & 0xFFFF;
-                    nb = e >> 16;
-                    v |= (uint64_t)((length - 3) & ((1u << extra) - 1)) << nb;
-                    nb += extra;
-                    v |= (uint64_t)(d & 0xFFFF) << nb;
-                    nb += d >> 16;
-                    v |= (uint64_t)(distance - (dm & 0xFFFF)) << nb;
-                    nb += dm >> 16;
-                }
+            }
+            if (EMIT) {
                 uint32_t total;
                 const uint32_t off = wave_excl_scan_u32(nb, (int)lane, total);
                 if ((uint64_t)total + (br.qbits - br.qflushed) > kEncTileBudget) br.flush(false);
-                br.or_bits128(br.qbits + off, v, 0);
+                br.or_bits128(br.qbits + off, v0, v1);
                 br.qbits += total;
                 if (br.qbits - br.qflushed > kEncRingBits / 2) br.flush(false);
             }
@@ -899,7 +941,7 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
     wave_sync();
 }
 
-__global__ __launch_bounds__(kWave) void deflate_write_kernel(GWriteArgs a) {
+__global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
     __shared__ GWriteLds lds;
     const int lane = threadIdx.x;
     const uint64_t sid = blockIdx.x;
@@ -913,7 +955,7 @@ __global__ __launch_bounds__(kWave) void deflate_write_kernel(GWriteArgs a) {
     }
     const GMatchRec* recs = a.matches + g_match_slice(off - in0, sid);
     const GBlockRec* blks = a.blocks + g_block_slice(off - in0, sid);
-    for (int i = lane; i < kEncRingDw; i += kWave) lds.ring[i] = 0;
+    for (int i = lane; i < kGRingDw; i += kWave) lds.ring[i] = 0;
     if (lane < 30) lds.dmeta[lane] = (uint32_t)kDistBase[lane] | ((uint32_t)kDistExtra[lane] << 16);
     wave_sync();
 

@@ -62,6 +62,10 @@ __device__ static const uint8_t kUfHeader[56] = {
 constexpr uint32_t kUfHeaderBits = 53 * 8 + 5;  // ultrafast.rs:87-88
 
 constexpr int kEncWaves = 4;             // wavefronts (= streams) per workgroup
+constexpr int kEncRingDw = 2048;         // 8 KiB bit ring per wavefront
+constexpr uint32_t kEncRingBits = kEncRingDw * 32;
+constexpr uint32_t kEncTileBudget = kEncRingBits - 1024;
+using BitRing = BitRingT<kEncRingDw>;
 
 struct EncLds {
     uint32_t tab[288];
