@@ -125,6 +125,17 @@ struct GParser {
     // would cost here.
     __device__ static uint32_t back_equal(const uint8_t* data, uint64_t a_end, uint64_t b_end, uint32_t limit) {
         uint32_t n = 0;
+        while (n + 32 <= limit) {  // four pairs of loads in flight
+            const uint8_t *pa = data + a_end - n, *pb = data + b_end - n;
+            const uint64_t x0 = g_load64(pa - 8) ^ g_load64(pb - 8), x1 = g_load64(pa - 16) ^ g_load64(pb - 16);
+            const uint64_t x2 = g_load64(pa - 24) ^ g_load64(pb - 24), x3 = g_load64(pa - 32) ^ g_load64(pb - 32);
+            if (x0 | x1 | x2 | x3) {
+                return n + (x0 ? (uint32_t)__builtin_clzll(x0) >> 3
+                            : x1 ? 8 + ((uint32_t)__builtin_clzll(x1) >> 3)
+                            : x2 ? 16 + ((uint32_t)__builtin_clzll(x2) >> 3) : 24 + ((uint32_t)__builtin_clzll(x3) >> 3));
+            }
+            n += 32;
+        }
         while (n + 8 <= limit) {
             const uint64_t x = g_load64(data + a_end - n - 8) ^ g_load64(data + b_end - n - 8);
             if (x) return n + ((uint32_t)__builtin_clzll(x) >> 3);
@@ -143,6 +154,15 @@ struct GParser {
     // any offset below limit.
     __device__ static uint32_t fwd_equal(const uint8_t* a, const uint8_t* b, uint32_t limit, bool wide_tail) {
         uint32_t k = 0;
+        for (; k + 32 <= limit; k += 32) {  // four pairs of loads in flight
+            const uint64_t x0 = g_load64(a + k) ^ g_load64(b + k), x1 = g_load64(a + k + 8) ^ g_load64(b + k + 8);
+            const uint64_t x2 = g_load64(a + k + 16) ^ g_load64(b + k + 16), x3 = g_load64(a + k + 24) ^ g_load64(b + k + 24);
+            if (x0 | x1 | x2 | x3) {
+                return k + (x0 ? (uint32_t)__builtin_ctzll(x0) >> 3
+                            : x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3)
+                            : x2 ? 16 + ((uint32_t)__builtin_ctzll(x2) >> 3) : 24 + ((uint32_t)__builtin_ctzll(x3) >> 3));
+            }
+        }
         for (; k + 8 <= limit; k += 8) {
             const uint64_t x = g_load64(a + k) ^ g_load64(b + k);
             if (x) return k + ((uint32_t)__builtin_ctzll(x) >> 3);
@@ -192,6 +212,18 @@ struct GParser {
             const uint64_t end = r.start - 1;  // the bytes tested are data[end - 1], data[end - 2], ...
             uint32_t n = 0;
             bool stop = false;
+            while (!stop && n + 32 <= limit) {  // four loads in flight
+                const uint8_t* pe = data + end - n;
+                const uint64_t x0 = g_load64(pe - 8) ^ v8, x1 = g_load64(pe - 16) ^ v8, x2 = g_load64(pe - 24) ^ v8, x3 = g_load64(pe - 32) ^ v8;
+                if (x0 | x1 | x2 | x3) {
+                    n += x0 ? (uint32_t)__builtin_clzll(x0) >> 3
+                         : x1 ? 8 + ((uint32_t)__builtin_clzll(x1) >> 3)
+                         : x2 ? 16 + ((uint32_t)__builtin_clzll(x2) >> 3) : 24 + ((uint32_t)__builtin_clzll(x3) >> 3);
+                    stop = true;
+                } else {
+                    n += 32;
+                }
+            }
             while (!stop && n + 8 <= limit) {
                 const uint64_t x = g_load64(data + end - n - 8) ^ v8;
                 if (x) {
@@ -313,42 +345,58 @@ struct GParser {
                     off[k] = hash[h[k]];
                 }
             }
+            // the unrolled part only finds the first step where something happens (and stores the
+            // table entries of the steps in front of it); what happens there is handled once, below
+            // -- one copy of the match code instead of kGroup keeps the kernel inside the
+            // instruction cache
+            int event = 0;  // 1 end of the scan range, 2 a run (RLE pattern), 3 a candidate from the table
+            uint64_t ev_p = 0, ev_cur = 0;
+            uint32_t ev_off = 0;
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                ip = p[k];
-                if (ip >= max_ip) return GMatch{0, 0, 0};
-                // ParserInner::get_match (parse/mod.rs:58-85), fizzle = false
-                const uint64_t current = cur[k];
-                if ((uint32_t)current == (uint32_t)(current >> 8)) {
-                    GT0(1);
-                    const GMatch r = rle_match(data, len);
-                    GT1(1);
-                    ip = r.end() - 3;
-                    return r;
-                }
-                if (!RLE) {  // HashTableMatchFinder::get_and_insert (hashtable.rs:16-50)
-                    uint32_t offset = off[k];
+                if (event == 0) {
+                    ev_p = p[k];
+                    ev_cur = cur[k];
+                    if (p[k] >= max_ip) {
+                        event = 1;
+                    } else if ((uint32_t)cur[k] == (uint32_t)(cur[k] >> 8)) {
+                        event = 2;
+                    } else if (!RLE) {  // HashTableMatchFinder::get_and_insert (hashtable.rs:16-50)
+                        uint32_t offset = off[k];
 #pragma unroll
-                    for (int j = 0; j < k; j++)
-                        if (h[j] == h[k]) offset = (uint32_t)p[j] + base_index;
-                    hash[h[k]] = (uint32_t)ip + base_index;
-                    const uint32_t sub = (uint32_t)ip > 32768 ? (uint32_t)ip - 32768 : 0;
-                    const uint32_t min_offset = max(base_index + sub, 1u);
-                    if (offset >= min_offset) {
-                        uint32_t l;
-                        uint64_t st;
-                        GT0(2);
-                        match_length8(current, data, len, last_match, ip, (uint64_t)(offset - base_index), l, st);
-                        GT1(2);
-                        if (l >= 8) {
-                            const GMatch r{l, (uint32_t)(ip - (uint64_t)(offset - base_index)), st};
-                            ip++;
-                            return r;
+                        for (int j = 0; j < k; j++)
+                            if (h[j] == h[k]) offset = (uint32_t)p[j] + base_index;
+                        hash[h[k]] = (uint32_t)p[k] + base_index;
+                        const uint32_t sub = (uint32_t)p[k] > 32768 ? (uint32_t)p[k] - 32768 : 0;
+                        if (offset >= max(base_index + sub, 1u)) {
+                            event = 3;
+                            ev_off = offset;
                         }
                     }
                 }
             }
-            ip = q;
+            if (event == 0) {
+                ip = q;
+                continue;
+            }
+            ip = ev_p;
+            if (event == 1) return GMatch{0, 0, 0};
+            // ParserInner::get_match (parse/mod.rs:58-85), fizzle = false
+            if (event == 2) {
+                GT0(1);
+                const GMatch r = rle_match(data, len);
+                GT1(1);
+                ip = r.end() - 3;
+                return r;
+            }
+            uint32_t l;
+            uint64_t st;
+            GT0(2);
+            match_length8(ev_cur, data, len, last_match, ip, (uint64_t)(ev_off - base_index), l, st);
+            GT1(2);
+            ip++;
+            if (l >= 8) return GMatch{l, (uint32_t)(ev_p - (uint64_t)(ev_off - base_index)), st};
+            ip += (ip - last_match) >> 5;
         }
         return GMatch{0, 0, 0};
     }
@@ -521,11 +569,15 @@ __global__ __launch_bounds__(kWave) void deflate_parse_kernel(GParseArgs a) {
         const uint64_t t_all = __builtin_readcyclecounter();
 #endif
         const uint64_t window = RLE ? 1 : 32768;
-        // Compressor::write_data (compress/mod.rs:126-159, no buffered input) ...
-        const uint64_t written = ps.compress<RLE>(input, len, 0, 0, false);
-        const uint64_t start = written > window ? written - window : 0;
-        // ... and Compressor::finish (:194-214) over the kept tail input.data = data[start..]
-        ps.compress<RLE>(input + start, len - start, (uint32_t)start, written - start, true);
+        // Compressor::write_data (compress/mod.rs:126-159, no buffered input), then Compressor::finish
+        // (:194-214) over the kept tail input.data = data[start..]; one copy of the parser's code
+        uint64_t written = 0, start = 0;
+#pragma nounroll
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass) start = written > window ? written - window : 0;
+            const uint64_t r = ps.compress<RLE>(input + start, len - start, (uint32_t)start, pass ? written - start : 0, pass != 0);
+            if (!pass) written = r;
+        }
         a.nblocks[sid] = ps.nblock;
 #ifdef FDH_DEBUG_GEN
         if (sid < 32768) {
