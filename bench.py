@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra encode / zlib-6 lines")
+    ap.add_argument("--general-streams", type=int, default=16384, help="streams given to the level-1 / RLE encoders (also lines)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline leg (4 legs)")
     ap.add_argument("--zlib6-streams", type=int, default=16384)
     ap.add_argument("--no-payload-gather", action="store_true")
@@ -452,6 +453,34 @@ def main():
                 del enc_out
             except Exception as e:
                 also.append({"workload": "BASELINE config 3 (encode)", "error": repr(e)})
+            # the general encoder (level 1, RLE) on the same buffers
+            for mode, label in ((fd.MODE_LEVEL1, "compress_to_vec (level 1, greedy parse + hash table)"),
+                                (fd.MODE_RLE, "compress_to_vec_rle (RLE parse)")):
+                try:
+                    ng = min(n, args.general_streams)
+                    gbound = (fd.compress_bound(L) + 15) & ~15
+                    g_off = torch.arange(ng + 1, dtype=torch.int64, device=dev) * gbound
+                    gout = torch.empty(ng * gbound, dtype=torch.uint8, device=dev)
+                    g_in, gr_off = raw[:ng].view(-1), r_off[:ng + 1]
+                    glen = fd.deflate_general_batch(g_in, gr_off, gout, g_off, mode)   # (returns when done)
+                    import zlib as _z
+                    for i in (0, ng // 2, ng - 1):   # sanity: the streams inflate back to the input
+                        c = gout[i * gbound:i * gbound + int(glen[i])].cpu().numpy().tobytes()
+                        assert _z.decompress(c) == raw[i].cpu().numpy().tobytes(), "general encoder stream %d" % i
+                    gsteps = 3
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(gsteps):
+                        fd.deflate_general_batch(g_in, gr_off, gout, g_off, mode, glen)
+                    barrier()
+                    gw = time.perf_counter() - t0
+                    also.append({"workload": "SURVEY 8f: %s of %d x %d KiB buffers" % (label, ng, L // 1024),
+                                 "metric": "input GB/s", "value": round(ng * L / (gw / gsteps) / 1e9, 3),
+                                 "ms_per_step": round(gw * 1e3 / gsteps, 4), "steps": gsteps,
+                                 "ratio": round(float(glen.to(torch.int64).sum()) / (ng * L), 4)})
+                    del gout
+                except Exception as e:
+                    also.append({"workload": "SURVEY 8f: %s" % label, "error": repr(e)})
             # BASELINE config 2 (ii): the same data as zlib level-6 streams (general kernels)
             try:
                 nz = min(n, args.zlib6_streams)

@@ -185,7 +185,9 @@ MODE_RLE = 2
 
 
 def deflate_general_batch(raw, in_off, out, out_off, mode, out_len=None):
-    """Level-1 / RLE encode of n buffers, one stream per lane (fdh_deflate_general_batch)."""
+    """Level-1 / RLE encode of n buffers (fdh_deflate_general_batch): a parser kernel (one stream per
+    lane) that records the back-references, then a block-writer kernel (one stream per wavefront).
+    Returns when the work has finished."""
     import torch
     n = in_off.numel() - 1
     if out_len is None:

@@ -127,7 +127,9 @@ int fdh_deflate_stored_batch(const uint8_t *in, const uint64_t *in_off, uint8_t 
 uint64_t fdh_stored_size(uint64_t len);
 
 /*
- * fdh_deflate_general_batch -- the general encoder on `n` buffers, one stream per LANE, bit-exact:
+ * fdh_deflate_general_batch -- the general encoder on `n` buffers, bit-exact (a parser kernel, one
+ * stream per lane, records the back-references and block ends; a block-writer kernel, one stream
+ * per wavefront, builds the Huffman codes and emits):
  *   FDH_MODE_LEVEL1  `compress_to_vec(input)` = `compress_to_vec_with_level(input, 1)`
  *                    (src/compress/mod.rs:294-303; Compressor::new(.., 1, true) :69-101 =
  *                    GreedyParser src/compress/parse/greedy.rs + HashTableMatchFinder
@@ -136,7 +138,9 @@ uint64_t fdh_stored_size(uint64_t len);
  *                    :107-123 = RleParser src/compress/parse/rle.rs)
  * Same argument convention as fdh_deflate_ultrafast_batch; slots of at least fdh_compress_bound(len_i)
  * bytes; out_len[i] = 0xFFFFFFFF if a slot was too small or the buffer exceeds 1 GiB.  The call
- * uses a per-device workspace (hash tables, symbol lists) and returns after the kernel has finished.
+ * uses a per-device workspace (one 256 KiB hash table per resident stream at level 1, at most
+ * 8 GiB; 8 bytes per 4 input bytes for the back-reference records), reads in_off[0] and in_off[n]
+ * back to size it, and returns after the kernels have finished.
  */
 #define FDH_MODE_LEVEL1 1u
 #define FDH_MODE_RLE 2u

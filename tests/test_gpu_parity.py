@@ -1,4 +1,5 @@
 """-m gpu: the HIP path, called through the C ABI, against the CPU oracle -- bit-exact."""
+import os
 import zlib
 
 import numpy as np
@@ -604,8 +605,11 @@ def test_mixed_batch_on_every_visible_device(harness):
 
 
 def test_general_encoder_level1_and_rle_bit_exact(harness):
-    """compress_to_vec (level 1) and compress_to_vec_rle on the GPU (one stream per lane) against the
-    oracle's restatement: bit-exact, batch and host conveniences, guard bytes behind every slot."""
+    """compress_to_vec (level 1) and compress_to_vec_rle on the GPU (parser kernel + block-writer
+    kernel) against the oracle's restatement: bit-exact, batch and host conveniences, guard bytes
+    behind every slot; inputs include several-block streams and trees that must be shortened to 15 /
+    7 bits.  The parser is run with 1, 8 and 64 streams per wavefront (FDH_GEN_LANES; the library
+    picks by batch size otherwise)."""
     import torch
     import fdeflate_amd as fd
     from test_oracle_golden import _encoder_inputs
@@ -624,15 +628,28 @@ def test_general_encoder_level1_and_rle_bit_exact(harness):
     d_in = torch.from_numpy(buf).cuda()
     d_in_off = torch.from_numpy(in_off.astype(np.int64)).cuda()
     d_out_off = torch.from_numpy(out_off).cuda()
-    for mode, enc in ((fd.MODE_LEVEL1, ob.compress_level1), (fd.MODE_RLE, ob.compress_rle)):
-        d_out = torch.full((int(out_off[-1]),), 0x5A, dtype=torch.uint8, device="cuda")
-        ln = fd.deflate_general_batch(d_in, d_in_off, d_out, d_out_off, mode).cpu().numpy().view(np.uint32)
-        h = d_out.cpu().numpy()
-        for i, raw in enumerate(raws):
-            exp = enc(raw)
-            got = h[out_off[i]:out_off[i] + int(ln[i])].tobytes()
-            assert got == exp, (mode, i, len(raw), int(ln[i]), len(exp))
-            assert np.all(h[out_off[i] + int(ln[i]):out_off[i + 1]] == 0x5A), (mode, i)
+    expect = {fd.MODE_LEVEL1: [ob.compress_level1(x) for x in raws], fd.MODE_RLE: [ob.compress_rle(x) for x in raws]}
+    old = os.environ.get("FDH_GEN_LANES")
+    try:
+        for lanes in (None, "1", "8", "64"):
+            if lanes is None:
+                os.environ.pop("FDH_GEN_LANES", None)
+            else:
+                os.environ["FDH_GEN_LANES"] = lanes
+            for mode in (fd.MODE_LEVEL1, fd.MODE_RLE):
+                d_out = torch.full((int(out_off[-1]),), 0x5A, dtype=torch.uint8, device="cuda")
+                ln = fd.deflate_general_batch(d_in, d_in_off, d_out, d_out_off, mode).cpu().numpy().view(np.uint32)
+                h = d_out.cpu().numpy()
+                for i, raw in enumerate(raws):
+                    exp = expect[mode][i]
+                    got = h[out_off[i]:out_off[i] + int(ln[i])].tobytes()
+                    assert got == exp, (lanes, mode, i, len(raw), int(ln[i]), len(exp))
+                    assert np.all(h[out_off[i] + int(ln[i]):out_off[i + 1]] == 0x5A), (lanes, mode, i)
+    finally:
+        if old is None:
+            os.environ.pop("FDH_GEN_LANES", None)
+        else:
+            os.environ["FDH_GEN_LANES"] = old
 
 
 def test_multi_gpu_entry_points_every_visible_device(harness):
