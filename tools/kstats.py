@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Average duration of the general encoder's kernels from a rocprofv3 --kernel-trace --stats --output-format csv
+directory: python tools/kstats.py <dir>"""
 import csv,glob,sys
 for f in glob.glob(sys.argv[1]+"/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
