@@ -288,7 +288,7 @@ def deflate_stored_batch(raw, in_off, out, out_off, out_len=None):
 
 
 def png_unfilter_batch(filt, filt_off, pix, pix_off, row_bytes, bpp, png_status=None):
-    """PNG scanline reconstruction of n images, one per lane (fdh_png_unfilter_batch)."""
+    """PNG scanline reconstruction of n images, one image per wavefront (fdh_png_unfilter_batch)."""
     import torch
     n = filt_off.numel() - 1
     if png_status is None:

@@ -698,33 +698,63 @@ def test_multi_gpu_entry_points_every_visible_device(harness):
         fd.shutdown_devices()
 
 
+def _png_round(fd, torch, r, bpp, max_rows):
+    row_bytes = bpp * int(r.integers(1, 90))
+    pixs, types = [], []
+    for k in range(70):
+        rows = int(r.integers(0, max_rows))
+        pixs.append(bytes(r.integers(0, 256 if k % 3 else 4, row_bytes * rows, dtype=np.uint8)))
+        types.append(bytes(r.integers(0, 5, rows, dtype=np.uint8)))
+    filts = [ob.png_filter(p, row_bytes, bpp, t)[1] for p, t in zip(pixs, types)]
+    pbuf, poff = streams.pack_exact(pixs)
+    tbuf, toff = streams.pack_exact(types)
+    fbuf, foff = streams.pack_exact(filts)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_p, d_po, d_t, d_to = d(pbuf), d(poff.astype(np.int64)), d(tbuf), d(toff.astype(np.int64))
+    d_fo = d(foff.astype(np.int64))
+    nf, npx = int(foff[-1]), int(poff[-1])
+    d_f = torch.full((nf + 64,), 0xEE, dtype=torch.uint8, device="cuda")      # 64 guard bytes behind
+    st = fd.png_filter_batch(d_p, d_po, d_t, d_to, d_f, d_fo, row_bytes, bpp)
+    h = d_f.cpu().numpy()
+    assert int(st.abs().sum()) == 0 and h[:nf].tobytes() == fbuf[:nf].tobytes() and np.all(h[nf:] == 0xEE)
+    d_out = torch.full((npx + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    st = fd.png_unfilter_batch(d(fbuf), d_fo, d_out, d_po, row_bytes, bpp)
+    h = d_out.cpu().numpy()
+    assert int(st.abs().sum()) == 0 and h[:npx].tobytes() == pbuf[:npx].tobytes() and np.all(h[npx:] == 0xEE)
+
+
 def test_png_filters_bit_exact_and_fused_decode(harness):
-    """PNG scanline reconstruction / filtering on the GPU (one image per lane)
-    against the oracle's restatement of the PNG specification, for every pixel size and ragged image
-    shapes; then the fused call: ultra-fast streams of filtered images -> decode -> reconstruct."""
+    """PNG scanline reconstruction / filtering on the GPU against the oracle's
+    restatement of the PNG specification, for every pixel size, ragged image shapes from 0 rows to
+    several 64-row bands, with both kernels (one image per wavefront, the default, and one image per
+    lane); then the fused call: ultra-fast streams of filtered images -> decode -> reconstruct."""
     import torch
     import fdeflate_amd as fd
-    r = np.random.default_rng(21)
-    for bpp in (1, 2, 3, 4, 6, 8):
-        row_bytes = bpp * int(r.integers(1, 90))
-        pixs, types = [], []
-        for k in range(70):
-            rows = int(r.integers(0, 12))
-            pixs.append(bytes(r.integers(0, 256 if k % 3 else 4, row_bytes * rows, dtype=np.uint8)))
-            types.append(bytes(r.integers(0, 5, rows, dtype=np.uint8)))
-        filts = [ob.png_filter(p, row_bytes, bpp, t)[1] for p, t in zip(pixs, types)]
-        pbuf, poff = streams.pack_exact(pixs)
-        tbuf, toff = streams.pack_exact(types)
-        fbuf, foff = streams.pack_exact(filts)
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-        d_p, d_po, d_t, d_to = d(pbuf), d(poff.astype(np.int64)), d(tbuf), d(toff.astype(np.int64))
-        d_fo = d(foff.astype(np.int64))
-        d_f = torch.full((max(int(foff[-1]), 1),), 0xEE, dtype=torch.uint8, device="cuda")
-        st = fd.png_filter_batch(d_p, d_po, d_t, d_to, d_f, d_fo, row_bytes, bpp)
-        assert int(st.abs().sum()) == 0 and d_f.cpu().numpy()[:int(foff[-1])].tobytes() == fbuf[:int(foff[-1])].tobytes()
-        d_out = torch.full((max(int(poff[-1]), 1),), 0xEE, dtype=torch.uint8, device="cuda")
-        st = fd.png_unfilter_batch(d(fbuf), d_fo, d_out, d_po, row_bytes, bpp)
-        assert int(st.abs().sum()) == 0 and d_out.cpu().numpy()[:int(poff[-1])].tobytes() == pbuf[:int(poff[-1])].tobytes()
+    old = os.environ.get("FDH_PNG_LANE_PER_IMAGE")
+    try:
+        for per_lane in ("0", "1"):
+            os.environ["FDH_PNG_LANE_PER_IMAGE"] = per_lane
+            r = np.random.default_rng(21)
+            for bpp in (1, 2, 3, 4, 6, 8):
+                _png_round(fd, torch, r, bpp, 12)
+                _png_round(fd, torch, r, bpp, 200)
+            # a bad filter type in a later band: rows in front of it are reconstructed, status 1
+            rows, rb = 150, 40
+            t = np.random.default_rng(5).integers(0, 5, rows, dtype=np.uint8)
+            pix = bytes(np.random.default_rng(6).integers(0, 256, rows * rb, dtype=np.uint8))
+            filt = bytearray(ob.png_filter(pix, rb, 4, bytes(t))[1])
+            filt[100 * (rb + 1)] = 9
+            d_out = torch.zeros(rows * rb, dtype=torch.uint8, device="cuda")
+            st = fd.png_unfilter_batch(torch.frombuffer(bytearray(filt), dtype=torch.uint8).cuda(),
+                                       torch.tensor([0, len(filt)], dtype=torch.int64, device="cuda"), d_out,
+                                       torch.tensor([0, rows * rb], dtype=torch.int64, device="cuda"), rb, 4)
+            assert st.cpu().tolist() == [1] and ob.png_unfilter(bytes(filt), rb, 4)[0] == 1
+            assert d_out.cpu().numpy()[:100 * rb].tobytes() == pix[:100 * rb]
+    finally:
+        if old is None:
+            os.environ.pop("FDH_PNG_LANE_PER_IMAGE", None)
+        else:
+            os.environ["FDH_PNG_LANE_PER_IMAGE"] = old
     # error statuses
     bad = [bytes([7, 1, 2, 3]), bytes([0, 1, 2])]
     bbuf, boff = streams.pack_exact(bad)
