@@ -324,7 +324,7 @@ struct GParser {
     // then the decisions one by one in order.  The loads of a group are issued before its stores, so
     // an entry that an earlier step of the same group would have replaced is patched from registers;
     // the steps behind a hit are dropped without having stored anything.
-    static constexpr int kGroup = 8;
+    static constexpr int kGroup = 16;
     template <bool RLE>
     __device__ GMatch advance_to_match(const uint8_t* data, uint64_t len, uint32_t base_index, uint64_t max_ip) {
         while (ip < max_ip) {
