@@ -185,6 +185,29 @@ def native_oracle(native_so):
     return L, how
 
 
+def cpu_general_encode(native_so, host_raw, rle, seconds):
+    """Input GB/s of the oracle's level-1 / RLE encoder on ONE host thread over the given buffers
+    (numpy uint8 [k, L]), repeated for about `seconds`."""
+    import ctypes as C
+    import numpy as np
+    lib, how = native_oracle(native_so)
+    fn = lib.fdo_compress_rle if rle else lib.fdo_compress_level1
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    k, L = host_raw.shape
+    cap = L + L // 2 + 1024
+    out = np.empty(cap, dtype=np.uint8)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for i in range(k):
+            if fn(host_raw[i].ctypes.data_as(C.c_void_p), L, out.ctypes.data_as(C.c_void_p), cap) == 0:
+                raise RuntimeError("oracle encoder failed")
+        done += k
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            return done * L / dt / 1e9, how
+
+
 def effective_cores():
     """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
     (the GPU boxes show 256 logical CPUs but run the job under a 16-CPU quota)."""
@@ -474,10 +497,15 @@ def main():
                         fd.deflate_general_batch(g_in, gr_off, gout, g_off, mode, glen)
                     barrier()
                     gw = time.perf_counter() - t0
-                    also.append({"workload": "SURVEY 8f: %s of %d x %d KiB buffers" % (label, ng, L // 1024),
-                                 "metric": "input GB/s", "value": round(ng * L / (gw / gsteps) / 1e9, 3),
-                                 "ms_per_step": round(gw * 1e3 / gsteps, 4), "steps": gsteps,
-                                 "ratio": round(float(glen.to(torch.int64).sum()) / (ng * L), 4)})
+                    entry = {"workload": "SURVEY 8f: %s of %d x %d KiB buffers" % (label, ng, L // 1024),
+                             "metric": "input GB/s", "value": round(ng * L / (gw / gsteps) / 1e9, 3),
+                             "ms_per_step": round(gw * 1e3 / gsteps, 4), "steps": gsteps,
+                             "ratio": round(float(glen.to(torch.int64).sum()) / (ng * L), 4)}
+                    if want_cpu:
+                        v, how = cpu_general_encode(native_so, raw[:64].cpu().numpy(), mode == fd.MODE_RLE, 1.5)
+                        entry["cpu_port_1_thread"] = {"value": round(v, 4), "unit": "GB/s", "kind": "port",
+                                                      "sample": "the first 64 buffers, repeated for 1.5 s; oracle (%s)" % how}
+                    also.append(entry)
                     del gout
                 except Exception as e:
                     also.append({"workload": "SURVEY 8f: %s" % label, "error": repr(e)})
