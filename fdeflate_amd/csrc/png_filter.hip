@@ -35,18 +35,25 @@ struct PngArgs {
     uint32_t row_bytes;
 };
 
+// Paeth predictor (PNG specification 9.4): p = a + b - c; the neighbour closest to p, ties in the
+// order a, b, c.  |p - a| = |b - c|, |p - b| = |a - c|, |p - c| = |a + b - 2c|: three
+// sum-of-absolute-differences instructions on byte values.
 __device__ __forceinline__ uint32_t png_paeth(uint32_t a, uint32_t b, uint32_t c) {
-    const int p = (int)a + (int)b - (int)c;
-    const int pa = abs(p - (int)a), pb = abs(p - (int)b), pc = abs(p - (int)c);
+    const uint32_t pa = __builtin_amdgcn_sad_u8(b, c, 0u), pb = __builtin_amdgcn_sad_u8(a, c, 0u);
+    const uint32_t pc = __builtin_amdgcn_sad_u16(a + b, c << 1, 0u);
     const uint32_t bc = pb <= pc ? b : c;
     return (pa <= pb && pa <= pc) ? a : bc;
 }
 
-struct PngMasks {  // 0xFF for the row's type, 0 otherwise: pred = OR of (candidate & mask)
-    uint32_t sub, up, avg, paeth;
-    __device__ explicit PngMasks(uint32_t t) : sub(t == 1 ? 0xFFu : 0u), up(t == 2 ? 0xFFu : 0u), avg(t == 3 ? 0xFFu : 0u), paeth(t == 4 ? 0xFFu : 0u) {}
+// The predictor of a row's type without branching on the type (lanes hold rows of different types):
+// None / Sub / Up / Average are (a * wa + b * wb) >> sh with per-row weights, Paeth is selected over it.
+struct PngMasks {
+    uint32_t wa, wb, sh;
+    bool paeth;
+    __device__ explicit PngMasks(uint32_t t) : wa(t == 1 || t == 3 ? 1u : 0u), wb(t == 2 || t == 3 ? 1u : 0u), sh(t == 3 ? 1u : 0u), paeth(t == 4) {}
     __device__ __forceinline__ uint32_t pred(uint32_t a, uint32_t b, uint32_t c) const {
-        return (a & sub) | (b & up) | (((a + b) >> 1) & avg) | (png_paeth(a, b, c) & paeth);
+        const uint32_t lin = (__umul24(a, wa) + __umul24(b, wb)) >> sh;
+        return paeth ? png_paeth(a, b, c) : lin;
     }
 };
 
@@ -183,9 +190,26 @@ __device__ __forceinline__ uint32_t png_from_lane_below(uint32_t x) {  // lane j
 // the chunk above it is what lane j - 1 produced one step earlier -- it arrives through a DPP lane
 // shift, not through memory (row 0 of a later band reads the last row of the band before from the
 // output).  Filtering has no such dependence (the predictors use raw neighbours): no skew, the row
-// above is read from the input.  Same per-chunk arithmetic as the lane-per-image kernel.
+// above is the chunk lane j - 1 read in the same step.  Same per-chunk arithmetic as the
+// lane-per-image kernel.
+//
+// Memory: with 16 bytes per lane per step and the rows 1 KiB or more apart, a wavefront touches 64
+// different cache lines per access and comes back to each of them eight times; with sixteen
+// wavefronts per CU the lines do not survive in the caches in between, and every 16 bytes cost a
+// whole line of traffic (measured: the kernel ran at the same speed with the arithmetic removed,
+// and with it doubled).  So every lane moves whole 128-byte lines: eight back-to-back loads fill a
+// register set one line ahead of the row's position, the set is parked in an LDS line buffer when
+// the row gets there, and the output goes through a second line buffer and leaves as eight
+// back-to-back stores when a line is complete.
+struct PngWaveLds {
+    uint4 lin[kWave][8];   // the 128-byte line of the row each lane is reading
+    uint4 lout[kWave][8];  // the line each lane is producing
+    uint4 lup[8];          // lane 0 of a later band: the line of the row above
+};
+
 template <int BPP, bool UNFILTER>
 __global__ __launch_bounds__(kWave) void png_wave_kernel(PngArgs a) {
+    __shared__ PngWaveLds lds;
     const uint64_t i = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     if (a.gate && a.gate[i] != 0) {
@@ -200,6 +224,18 @@ __global__ __launch_bounds__(kWave) void png_wave_kernel(PngArgs a) {
     if (rows * src_row != s1 - s0 || rows * dst_row > d1 - d0) st = 2;
     if (!UNFILTER && st == 0 && a.types_off[i + 1] - a.types_off[i] < rows) st = 2;
     const uint32_t nchunks = (uint32_t)((rb + 15) / 16);
+    const uint8_t* const src_end = a.src + s1;
+    const uint8_t* const dst_end = a.dst + d0 + rows * dst_row;
+    // the eight 16-byte pieces of line `ln` of the row at `row`; reads stay below `end`
+    auto fetch = [&](const uint8_t* row, const uint8_t* end, uint32_t ln, uint4(&regs)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint64_t o = (uint64_t)ln * 128 + (uint64_t)k * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o < rb) v = row + o + 16 <= end ? png_load16(row + o) : png_load_part(row + o, (uint32_t)min((uint64_t)16, rb - o));
+            regs[k] = v;
+        }
+    };
     for (uint64_t r0 = 0; r0 < rows && st == 0; r0 += kWave) {
         const uint64_t r = r0 + lane;
         const bool have = r < rows;
@@ -220,22 +256,52 @@ __global__ __launch_bounds__(kWave) void png_wave_kernel(PngArgs a) {
         uint32_t la[8], ua[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) la[k] = ua[k] = 0;
-        uint4 last = make_uint4(0, 0, 0, 0);  // the chunk this lane produced in the step before
+        // the row above lane 0's row, from memory: the output of the band before / the raw input
+        const bool from_memory = lane == 0 && r > 0;
+        const uint8_t* const uprow = (UNFILTER ? out : in) - rb;
+        const uint8_t* const upend = UNFILTER ? dst_end : src_end;
+        uint4 pf[8];  // the line behind the one in lds.lin
+        if (mine) {
+            fetch(in, src_end, 0, pf);
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds.lin[lane][k] = pf[k];
+            fetch(in, src_end, 1, pf);
+        }
+        uint4 last = make_uint4(0, 0, 0, 0);  // what the lane below needs: this lane's output / input chunk
         const uint32_t steps = band ? nchunks + (UNFILTER ? band - 1 : 0) : 0;
         for (uint32_t step = 0; step < steps; step++) {
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (UNFILTER) u = make_uint4(png_from_lane_below(last.x), png_from_lane_below(last.y), png_from_lane_below(last.z), png_from_lane_below(last.w));
             const uint32_t c = step - (UNFILTER ? lane : 0);  // (wraps for the lanes that have not started)
-            if (mine && c < nchunks) {
-                const uint32_t valid = (uint32_t)min((uint64_t)16, rb - (uint64_t)c * 16);
-                if (UNFILTER ? lane == 0 : true) {
-                    // the row above from memory: the output of the band before / the raw input
-                    u = make_uint4(0, 0, 0, 0);
-                    if (r > 0) u = png_load_part((UNFILTER ? out : in) - rb + (uint64_t)c * 16, valid);
+            const bool on = mine && c < nchunks;
+            if (on && (c & 7) == 0) {  // entering a line
+                if (c) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) lds.lin[lane][k] = pf[k];
+                    fetch(in, src_end, (c >> 3) + 1, pf);
                 }
-                const uint4 f = png_load_part(in + (uint64_t)c * 16, valid);
-                last = png_chunk<BPP, UNFILTER>(f, u, la, ua, m);
-                png_store_part(out + (uint64_t)c * 16, last, valid);
+                if (from_memory) {
+                    uint4 up[8];
+                    fetch(uprow, upend, c >> 3, up);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) lds.lup[k] = up[k];
+                }
+            }
+            uint4 f = make_uint4(0, 0, 0, 0);
+            if (on) f = lds.lin[lane][c & 7];
+            if (!UNFILTER) last = f;
+            uint4 u = make_uint4(png_from_lane_below(last.x), png_from_lane_below(last.y), png_from_lane_below(last.z), png_from_lane_below(last.w));
+            if (on) {
+                if (lane == 0) u = r > 0 ? lds.lup[c & 7] : make_uint4(0, 0, 0, 0);
+                const uint4 o = png_chunk<BPP, UNFILTER>(f, u, la, ua, m);
+                if (UNFILTER) last = o;
+                lds.lout[lane][c & 7] = o;
+                if ((c & 7) == 7 || c == nchunks - 1) {  // the line is complete: out it goes
+                    const uint64_t base = (uint64_t)(c >> 3) * 128;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint64_t o16 = base + (uint64_t)k * 16;
+                        if ((uint32_t)k <= (c & 7) && o16 < rb) png_store_part(out + o16, lds.lout[lane][k], (uint32_t)min((uint64_t)16, rb - o16));
+                    }
+                }
             }
         }
         // the next band's first row reads this band's last row back
