@@ -18,6 +18,7 @@
 // diverge.  Filtering has no such dependence (the predictors use raw neighbours).
 #include "device_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace fdh {
@@ -311,6 +312,195 @@ __global__ __launch_bounds__(kWave) void png_wave_kernel(PngArgs a) {
     if (lane == 0) a.status[i] = st;
 }
 
+// ---- reconstruction as one pipeline over many images ------------------------------------------
+//
+// png_wave_kernel pays for its skew twice on small images: a band of 64 rows of N chunks takes
+// N + 63 steps (half the lane-steps idle for the bench's 64-chunk rows), and because every lane
+// crosses its 128-byte line boundaries at a different step, every step issues the line loads and
+// stores for an eighth of the lanes (the CU's one address unit ends up the busiest unit).  Here
+// the rows of `per_wave` consecutive images form ONE sequence R = 0, 1, 2, ...: row R belongs to
+// lane R % 64 and starts at step (R % 64) + (R / 64) * P, P = max(N rounded up to 8, 64), so a lane
+// goes from one of its rows to the next without waiting and the ramp is paid once per wavefront.
+// The row above is still one lane below and one step ahead (lane 63 hands its chunks to lane 0
+// through an LDS row buffer, P - 63 steps ahead); the first row of an image has no row above.
+// Memory moves at wavefront-uniform steps: every eighth step each lane parks the line it fetched
+// eight steps ago in its double-buffered LDS line, fetches the line it will enter next, and writes
+// out the line it completed last -- eight full-width loads and stores per eight steps.
+constexpr uint32_t kPipeMaxChunks = 256;  // rows up to 4 KiB (the LDS row buffer)
+constexpr uint32_t kPipeMaxImages = 8;
+constexpr int kSlot = 4;  // 16-byte chunks per line slot (64 bytes): 20 KiB of LDS per wavefront, two wavefronts per SIMD
+
+struct PngPipeLds {
+    uint4 lin[kWave][2][kSlot];
+    uint4 lout[kWave][2][kSlot];
+    uint4 rowbuf[kPipeMaxChunks];
+    uint64_t sbase[kPipeMaxImages + 1], dbase[kPipeMaxImages];  // offsets of the images' buffers (sbase[j + 1]: end of j's)
+    uint32_t rowsum[kPipeMaxImages + 1];
+    uint32_t bad[kPipeMaxImages];  // first row with a bad filter type, per image
+};
+
+struct PngPipeRow {  // one row of the sequence, as a lane sees it
+    const uint8_t* in;  // first filtered byte (behind the type byte)
+    uint8_t* out;
+    uint32_t r, img;    // row in its image; image slot in the wavefront
+    uint32_t type;
+    bool valid;         // the sequence has this row
+    bool produced;      // ... and it is reconstructed (no bad filter type at or before it)
+};
+
+template <int BPP>
+__global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per_wave) {
+    __shared__ PngPipeLds lds;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t img0 = (uint64_t)blockIdx.x * per_wave;
+    const uint32_t cnt = (uint32_t)min((uint64_t)per_wave, a.n - img0);
+    const uint64_t rb = a.row_bytes;
+    const uint32_t N = (uint32_t)((rb + 15) / 16);
+    const uint32_t P = max((N + 7) & ~7u, (uint32_t)kWave);
+    // ---- the images of this wavefront: row counts, statuses ----
+    uint32_t my_rows = 0, my_st = 0;
+    if (lane < cnt) {
+        const uint64_t i = img0 + lane;
+        if (a.gate && a.gate[i] != 0) {
+            my_st = 3;
+        } else {
+            const uint64_t fl = a.src_off[i + 1] - a.src_off[i], pl = a.dst_off[i + 1] - a.dst_off[i];
+            const uint64_t rows = fl / (rb + 1);
+            if (rows * (rb + 1) != fl || rows * rb > pl) my_st = 2;
+            else my_rows = (uint32_t)rows;
+        }
+        lds.bad[lane] = 0xFFFFFFFFu;
+        lds.sbase[lane] = a.src_off[i];
+        lds.dbase[lane] = a.dst_off[i];
+        if (lane + 1 == cnt) lds.sbase[cnt] = a.src_off[i + 1];
+    }
+    {   // prefix sums of the row counts (at most eight images: by hand)
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < cnt; j++) {
+            if (lane == 0) lds.rowsum[j] = sum;
+            sum += (uint32_t)__builtin_amdgcn_readlane((int)my_rows, (int)j);
+        }
+        if (lane == 0) lds.rowsum[cnt] = sum;
+    }
+    wave_sync();
+    const uint32_t T = lds.rowsum[cnt];
+    auto describe = [&](uint32_t R) -> PngPipeRow {
+        PngPipeRow d{nullptr, nullptr, 0, 0, 0, false, false};
+        if (R >= T) return d;
+        uint32_t j = 0;
+        while (j + 1 < cnt && lds.rowsum[j + 1] <= R) j++;
+        d.r = R - lds.rowsum[j];
+        d.img = j;
+        d.in = a.src + lds.sbase[j] + (uint64_t)d.r * (rb + 1) + 1;  // (no global load on the way to the type byte's address)
+        d.out = a.dst + lds.dbase[j] + (uint64_t)d.r * rb;
+        d.type = d.in[-1];
+        d.valid = true;
+        return d;
+    };
+    // reads of a row's lines stay inside its image's filtered bytes (+ the next row's, harmless)
+    auto fetch = [&](const PngPipeRow& d, uint32_t ln, uint4(&regs)[kSlot]) {
+        const uint8_t* const end = a.src + lds.sbase[d.img + 1];
+#pragma unroll
+        for (int k = 0; k < kSlot; k++) {
+            const uint64_t o = (uint64_t)ln * (16 * kSlot) + (uint64_t)k * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (d.valid && o < rb) v = d.in + o + 16 <= end ? png_load16(d.in + o) : png_load_part(d.in + o, (uint32_t)min((uint64_t)16, rb - o));
+            regs[k] = v;
+        }
+    };
+    PngPipeRow prev{nullptr, nullptr, 0, 0, 0, false, false}, cur = prev, next = describe(lane);
+    // position in the period of row k (signed: negative long before the lane's first row); it reaches
+    // P (= 0 of the next row) after lane + 16 steps -- two uniform steps ahead of the first chunk, one
+    // to fetch its line and one to park it
+    int32_t c = (int32_t)P - (int32_t)lane - 2 * kSlot;
+    uint32_t k = 0xFFFFFFFFu;  // rows of this lane started so far, minus one
+    uint32_t la[8], ua[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) la[q] = ua[q] = 0;
+    PngMasks m(0);
+    uint4 pf[kSlot], last = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < kSlot; q++) pf[q] = make_uint4(0, 0, 0, 0);
+    const uint32_t kmax = T ? (T - 1) / kWave : 0;
+    // the last slot of the last row ends before step kmax * P + 63 + 16 + (N rounded up to 8); the
+    // uniform step behind that writes its line
+    const uint32_t steps = T ? ((kmax * P + kWave + 2 * kSlot + ((N + 7) & ~7u) + 7) & ~7u) + 1 : 0;
+    for (uint32_t step = 0; step < steps; step++) {
+        if (c == (int32_t)P) {  // this lane starts its next row
+            c = 0;
+            k++;
+            prev = cur;
+            cur = next;
+            next = describe((k + 1) * kWave + lane);
+            if (cur.valid) {
+                if (cur.type > 4) atomicMin(&lds.bad[cur.img], cur.r);
+                cur.produced = cur.type <= 4 && cur.r < lds.bad[cur.img];
+            }
+            m = PngMasks(cur.type);
+#pragma unroll
+            for (int q = 0; q < 8; q++) la[q] = ua[q] = 0;
+        }
+        if ((step & (kSlot - 1)) == 0) {
+            const int32_t ph = c & (kSlot - 1);
+            {   // park the line fetched eight steps ago: the slot entered in (step, step + 8]
+                const int32_t d1 = ph ? kSlot - ph : kSlot;
+                int32_t c1 = c + d1;
+                uint32_t k1 = k;
+                if (c1 >= (int32_t)P) {
+                    c1 -= (int32_t)P;
+                    k1++;
+                }
+                const uint32_t par = (k1 * (P / kSlot) + ((uint32_t)c1 / kSlot)) & 1;
+#pragma unroll
+                for (int q = 0; q < kSlot; q++) lds.lin[lane][par][q] = pf[q];
+            }
+            {   // fetch the line of the slot entered in (step + 8, step + 16]
+                const int32_t d2 = ph ? 2 * kSlot - ph : 2 * kSlot;
+                int32_t c2 = c + d2;
+                const bool wrap = c2 >= (int32_t)P;
+                if (wrap) c2 -= (int32_t)P;
+                const PngPipeRow& d = wrap ? next : cur;
+                if ((uint32_t)c2 < N) {
+                    fetch(d, (uint32_t)c2 / kSlot, pf);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < kSlot; q++) pf[q] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            {   // write out the line of the slot that ended in (step - 8, step]
+                int32_t cfs = c - ph - kSlot;
+                const bool back = cfs < 0;  // (that slot belongs to the row before)
+                if (back) cfs += (int32_t)P;
+                const PngPipeRow& d = back ? prev : cur;
+                const uint32_t kf = back ? k - 1 : k;
+                const uint32_t cf = (uint32_t)cfs;
+                if (d.valid && d.produced && cf < N) {
+                    const uint32_t par = (kf * (P / kSlot) + (cf / kSlot)) & 1;
+#pragma unroll
+                    for (int q = 0; q < kSlot; q++) {
+                        const uint64_t o16 = (uint64_t)(cf + q) * 16;
+                        if (cf + q < N && o16 < rb) png_store_part(d.out + o16, lds.lout[lane][par][q], (uint32_t)min((uint64_t)16, rb - o16));
+                    }
+                }
+            }
+        }
+        const uint32_t cu = (uint32_t)c;
+        const bool on = cur.valid && cur.produced && cu < N;  // (cur.valid is false while c is negative)
+        const uint32_t par = (k * (P / kSlot) + (cu / kSlot)) & 1;
+        uint4 u = make_uint4(png_from_lane_below(last.x), png_from_lane_below(last.y), png_from_lane_below(last.z), png_from_lane_below(last.w));
+        if (on) {
+            const uint4 f = lds.lin[lane][par][cu & (kSlot - 1)];
+            if (lane == 0) u = lds.rowbuf[cu];
+            if (cur.r == 0) u = make_uint4(0, 0, 0, 0);
+            last = png_chunk<BPP, true>(f, u, la, ua, m);
+            lds.lout[lane][par][cu & (kSlot - 1)] = last;
+            if (lane == kWave - 1) lds.rowbuf[cu] = last;
+        }
+        c++;
+    }
+    if (lane < cnt) a.status[img0 + lane] = my_st ? my_st : (lds.bad[lane] != 0xFFFFFFFFu ? 1u : 0u);
+}
+
 }  // namespace fdh
 
 // One image per wavefront by default; FDH_PNG_LANE_PER_IMAGE=1 selects the one-image-per-lane
@@ -320,12 +510,19 @@ static int png_launch(const fdh::PngArgs& a, uint32_t bpp, hipStream_t stream) {
     if (a.n == 0) return 0;
     const char* e = getenv("FDH_PNG_LANE_PER_IMAGE");
     const bool per_lane = e && e[0] == '1';
+    const char* e2 = getenv("FDH_PNG_NO_PIPELINE");
+    // reconstruction of rows up to 4 KiB: the pipeline over several images per wavefront (more of
+    // them when the batch is large enough to fill the GPU anyway)
+    const bool pipe = UNFILTER && !per_lane && !(e2 && e2[0] == '1') && a.row_bytes <= 16 * fdh::kPipeMaxChunks;
+    const uint32_t per_wave = (uint32_t)std::min<uint64_t>(fdh::kPipeMaxImages, std::max<uint64_t>(1, a.n / 4096));
     const dim3 block(fdh::kWave);
-    const dim3 grid(per_lane ? (unsigned)((a.n + fdh::kWave - 1) / fdh::kWave) : (unsigned)a.n);
+    const dim3 grid(per_lane ? (unsigned)((a.n + fdh::kWave - 1) / fdh::kWave) : pipe ? (unsigned)((a.n + per_wave - 1) / per_wave) : (unsigned)a.n);
 #define FDH_PNG_CASE(B)                                                                                  \
     case B:                                                                                              \
         if (per_lane)                                                                                    \
             hipLaunchKernelGGL((fdh::png_filter_kernel<B, UNFILTER>), grid, block, 0, stream, a);        \
+        else if (pipe)                                                                                   \
+            hipLaunchKernelGGL((fdh::png_pipe_kernel<B>), grid, block, 0, stream, a, per_wave);          \
         else                                                                                             \
             hipLaunchKernelGGL((fdh::png_wave_kernel<B, UNFILTER>), grid, block, 0, stream, a);          \
         break;
