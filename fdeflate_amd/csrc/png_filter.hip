@@ -50,11 +50,11 @@ __device__ __forceinline__ uint32_t png_paeth(uint32_t a, uint32_t b, uint32_t c
 // None / Sub / Up / Average are (a * wa + b * wb) >> sh with per-row weights, Paeth is selected over it.
 struct PngMasks {
     uint32_t wa, wb, sh;
-    bool paeth;
-    __device__ explicit PngMasks(uint32_t t) : wa(t == 1 || t == 3 ? 1u : 0u), wb(t == 2 || t == 3 ? 1u : 0u), sh(t == 3 ? 1u : 0u), paeth(t == 4) {}
+    uint32_t paeth;  // all ones for a Paeth row: the select is a bit-field insert, not a branch per byte
+    __device__ explicit PngMasks(uint32_t t) : wa(t == 1 || t == 3 ? 1u : 0u), wb(t == 2 || t == 3 ? 1u : 0u), sh(t == 3 ? 1u : 0u), paeth(t == 4 ? 0xFFFFFFFFu : 0u) {}
     __device__ __forceinline__ uint32_t pred(uint32_t a, uint32_t b, uint32_t c) const {
         const uint32_t lin = (__umul24(a, wa) + __umul24(b, wb)) >> sh;
-        return paeth ? png_paeth(a, b, c) : lin;
+        return (png_paeth(a, b, c) & paeth) | (lin & ~paeth);
     }
 };
 
@@ -384,14 +384,16 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
     }
     wave_sync();
     const uint32_t T = lds.rowsum[cnt];
-    auto describe = [&](uint32_t R) -> PngPipeRow {
+    // A lane's rows come in increasing order: the image is searched on from the one of its last row.
+    // (One lane starts a row at every step, so this runs at every step: kept short, and without a
+    // global load on the way to the type byte's address.)
+    auto describe = [&](uint32_t R, uint32_t j) -> PngPipeRow {
         PngPipeRow d{nullptr, nullptr, 0, 0, 0, false, false};
         if (R >= T) return d;
-        uint32_t j = 0;
-        while (j + 1 < cnt && lds.rowsum[j + 1] <= R) j++;
+        while (lds.rowsum[j + 1] <= R) j++;  // (R < T = rowsum[cnt] ends it)
         d.r = R - lds.rowsum[j];
         d.img = j;
-        d.in = a.src + lds.sbase[j] + (uint64_t)d.r * (rb + 1) + 1;  // (no global load on the way to the type byte's address)
+        d.in = a.src + lds.sbase[j] + (uint64_t)d.r * (rb + 1) + 1;
         d.out = a.dst + lds.dbase[j] + (uint64_t)d.r * rb;
         d.type = d.in[-1];
         d.valid = true;
@@ -400,6 +402,11 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
     // reads of a row's lines stay inside its image's filtered bytes (+ the next row's, harmless)
     auto fetch = [&](const PngPipeRow& d, uint32_t ln, uint4(&regs)[kSlot]) {
         const uint8_t* const end = a.src + lds.sbase[d.img + 1];
+        if (d.valid && (uint64_t)(ln + 1) * (16 * kSlot) <= rb) {  // a line inside the row: plain loads
+#pragma unroll
+            for (int k = 0; k < kSlot; k++) regs[k] = png_load16(d.in + (uint64_t)ln * (16 * kSlot) + (uint64_t)k * 16);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < kSlot; k++) {
             const uint64_t o = (uint64_t)ln * (16 * kSlot) + (uint64_t)k * 16;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
             regs[k] = v;
         }
     };
-    PngPipeRow prev{nullptr, nullptr, 0, 0, 0, false, false}, cur = prev, next = describe(lane);
+    PngPipeRow prev{nullptr, nullptr, 0, 0, 0, false, false}, cur = prev, next = describe(lane, 0);
     // position in the period of row k (signed: negative long before the lane's first row); it reaches
     // P (= 0 of the next row) after lane + 16 steps -- two uniform steps ahead of the first chunk, one
     // to fetch its line and one to park it
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
             k++;
             prev = cur;
             cur = next;
-            next = describe((k + 1) * kWave + lane);
+            next = describe((k + 1) * kWave + lane, cur.img);
             if (cur.valid) {
                 if (cur.type > 4) atomicMin(&lds.bad[cur.img], cur.r);
                 cur.produced = cur.type <= 4 && cur.r < lds.bad[cur.img];
@@ -476,6 +483,10 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
                 const uint32_t cf = (uint32_t)cfs;
                 if (d.valid && d.produced && cf < N) {
                     const uint32_t par = (kf * (P / kSlot) + (cf / kSlot)) & 1;
+                    if ((uint64_t)(cf + kSlot) * 16 <= rb) {  // a line inside the row: plain stores
+#pragma unroll
+                        for (int q = 0; q < kSlot; q++) png_store16(d.out + (uint64_t)(cf + q) * 16, lds.lout[lane][par][q]);
+                    } else
 #pragma unroll
                     for (int q = 0; q < kSlot; q++) {
                         const uint64_t o16 = (uint64_t)(cf + q) * 16;
@@ -514,7 +525,11 @@ static int png_launch(const fdh::PngArgs& a, uint32_t bpp, hipStream_t stream) {
     // reconstruction of rows up to 4 KiB: the pipeline over several images per wavefront (more of
     // them when the batch is large enough to fill the GPU anyway)
     const bool pipe = UNFILTER && !per_lane && !(e2 && e2[0] == '1') && a.row_bytes <= 16 * fdh::kPipeMaxChunks;
-    const uint32_t per_wave = (uint32_t)std::min<uint64_t>(fdh::kPipeMaxImages, std::max<uint64_t>(1, a.n / 4096));
+    uint32_t per_wave = (uint32_t)std::min<uint64_t>(fdh::kPipeMaxImages, std::max<uint64_t>(1, a.n / 4096));
+    if (const char* e3 = getenv("FDH_PNG_IMAGES_PER_WAVE")) {  // (tests: the multi-image pipeline on small batches)
+        const int v = atoi(e3);
+        if (v >= 1 && v <= (int)fdh::kPipeMaxImages) per_wave = (uint32_t)v;
+    }
     const dim3 block(fdh::kWave);
     const dim3 grid(per_lane ? (unsigned)((a.n + fdh::kWave - 1) / fdh::kWave) : pipe ? (unsigned)((a.n + per_wave - 1) / per_wave) : (unsigned)a.n);
 #define FDH_PNG_CASE(B)                                                                                  \

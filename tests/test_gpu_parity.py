@@ -698,8 +698,8 @@ def test_multi_gpu_entry_points_every_visible_device(harness):
         fd.shutdown_devices()
 
 
-def _png_round(fd, torch, r, bpp, max_rows):
-    row_bytes = bpp * int(r.integers(1, 90))
+def _png_round(fd, torch, r, bpp, max_rows, wide=False):
+    row_bytes = bpp * int(r.integers(1, 90)) if not wide else bpp * int(r.integers(4200 // bpp, 5000 // bpp))
     pixs, types = [], []
     for k in range(70):
         rows = int(r.integers(0, max_rows))
@@ -726,18 +726,24 @@ def _png_round(fd, torch, r, bpp, max_rows):
 def test_png_filters_bit_exact_and_fused_decode(harness):
     """PNG scanline reconstruction / filtering on the GPU against the oracle's
     restatement of the PNG specification, for every pixel size, ragged image shapes from 0 rows to
-    several 64-row bands, with both kernels (one image per wavefront, the default, and one image per
-    lane); then the fused call: ultra-fast streams of filtered images -> decode -> reconstruct."""
+    several 64-row bands, with every kernel (the pipeline over several images per wavefront, the
+    default for reconstruction; one image per wavefront; one image per lane); then the fused call:
+    ultra-fast streams of filtered images -> decode -> reconstruct."""
     import torch
     import fdeflate_amd as fd
     old = os.environ.get("FDH_PNG_LANE_PER_IMAGE")
+    old2 = os.environ.get("FDH_PNG_NO_PIPELINE")
+    old3 = os.environ.get("FDH_PNG_IMAGES_PER_WAVE")
     try:
-        for per_lane in ("0", "1"):
+        for per_lane, no_pipe, per_wave in (("0", "0", "1"), ("0", "0", "3"), ("0", "0", "8"), ("0", "1", "1"), ("1", "0", "1")):
             os.environ["FDH_PNG_LANE_PER_IMAGE"] = per_lane
+            os.environ["FDH_PNG_NO_PIPELINE"] = no_pipe
+            os.environ["FDH_PNG_IMAGES_PER_WAVE"] = per_wave
             r = np.random.default_rng(21)
             for bpp in (1, 2, 3, 4, 6, 8):
                 _png_round(fd, torch, r, bpp, 12)
                 _png_round(fd, torch, r, bpp, 200)
+            _png_round(fd, torch, r, 4, 70, wide=True)   # rows above 4 KiB: not the pipeline's
             # a bad filter type in a later band: rows in front of it are reconstructed, status 1
             rows, rb = 150, 40
             t = np.random.default_rng(5).integers(0, 5, rows, dtype=np.uint8)
@@ -751,10 +757,11 @@ def test_png_filters_bit_exact_and_fused_decode(harness):
             assert st.cpu().tolist() == [1] and ob.png_unfilter(bytes(filt), rb, 4)[0] == 1
             assert d_out.cpu().numpy()[:100 * rb].tobytes() == pix[:100 * rb]
     finally:
-        if old is None:
-            os.environ.pop("FDH_PNG_LANE_PER_IMAGE", None)
-        else:
-            os.environ["FDH_PNG_LANE_PER_IMAGE"] = old
+        for name, val in (("FDH_PNG_LANE_PER_IMAGE", old), ("FDH_PNG_NO_PIPELINE", old2), ("FDH_PNG_IMAGES_PER_WAVE", old3)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
     # error statuses
     bad = [bytes([7, 1, 2, 3]), bytes([0, 1, 2])]
     bbuf, boff = streams.pack_exact(bad)
