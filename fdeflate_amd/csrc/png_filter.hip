@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kWave) void png_wave_kernel(PngArgs a) {
 // out the line it completed last -- eight full-width loads and stores per eight steps.
 constexpr uint32_t kPipeMaxChunks = 256;  // rows up to 4 KiB (the LDS row buffer)
 constexpr uint32_t kPipeMaxImages = 8;
-constexpr int kSlot = 4;  // 16-byte chunks per line slot (64 bytes): 20 KiB of LDS per wavefront, two wavefronts per SIMD
+constexpr int kSlot = 2;  // 16-byte chunks per line slot (32 bytes): 12 KiB of LDS per wavefront, 13 wavefronts per CU
 
 struct PngPipeLds {
     uint4 lin[kWave][2][kSlot];
