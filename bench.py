@@ -509,6 +509,39 @@ def main():
                     del gout
                 except Exception as e:
                     also.append({"workload": "SURVEY 8f: %s" % label, "error": repr(e)})
+            # decode + PNG scanline reconstruction in one call (the buffers are
+            # 64 scanlines of 1023 bytes behind a filter-type byte each, RGB8)
+            try:
+                from fdeflate_amd import synth as _synth
+                rb_png, bpp_png = _synth.ROW_BYTES - 1, 3
+                rows_png = L // _synth.ROW_BYTES
+                assert rows_png * _synth.ROW_BYTES == L
+                p_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * (rows_png * rb_png)
+                pix = torch.empty(n * rows_png * rb_png, dtype=torch.uint8, device=dev)
+
+                def png_step():
+                    return fd.inflate_png_batch(comp, c_off, out, r_off, pix, p_off, rb_png, bpp_png)
+
+                _, pst_status, _, pst = png_step()
+                barrier()
+                assert int(pst_status.abs().sum()) == 0 and int(pst.abs().sum()) == 0, "png decode statuses"
+                # property check: filtering the reconstructed pixels with the rows' own filter types
+                # gives the decoded scanlines back
+                types = out.view(n, rows_png, rb_png + 1)[:, :, 0].contiguous().view(-1)
+                t_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * rows_png
+                back = torch.empty_like(out)
+                fst = fd.png_filter_batch(pix, p_off, types, t_off, back, r_off, rb_png, bpp_png)
+                assert int(fst.abs().sum()) == 0 and torch.equal(back, out), "filter(reconstruct(x)) != x"
+                del back, types
+                psteps = max(3, args.steps // 4)
+                w4, _k4 = time_steps(png_step, psteps, 1, barrier)
+                also.append({"workload": "SURVEY 8f: inflate + PNG scanline reconstruction (fdh_inflate_png_batch) of the same "
+                                         "%d streams, %d rows x %d bytes, %d bytes per pixel" % (n, rows_png, rb_png, bpp_png),
+                             "metric": "decompressed GB/s", "value": round(n * L / (w4 / psteps) / 1e9, 3),
+                             "ms_per_step": round(w4 * 1e3 / psteps, 4), "steps": psteps})
+                del pix
+            except Exception as e:
+                also.append({"workload": "SURVEY 8f: inflate + PNG reconstruction", "error": repr(e)})
             # BASELINE config 2 (ii): the same data as zlib level-6 streams (general kernels)
             try:
                 nz = min(n, args.zlib6_streams)
