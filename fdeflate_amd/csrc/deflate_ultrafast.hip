@@ -172,14 +172,20 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
     uint32_t carry = 0;  // pending run (zero bytes) entering the tile; may exceed 2^32? len < 2^32 assumed below
     // the chunk of the NEXT tile is requested while this one is encoded (the loads are the only
     // global-memory latency of the loop)
+    // The load of the next tile's chunk is UNCONDITIONAL (lanes past the end re-read the last chunk
+    // and drop it): behind a load in a branch the compiler cannot know how many loads are in flight
+    // and waits for all of them -- the prefetch it had just issued included -- at the join, which
+    // put a full trip to memory into every tile.
+    const uint64_t last_chunk = nchunks ? nchunks - 1 : 0;
     uint64_t x_next = 0;
-    if ((uint64_t)lane < nchunks) x_next = *reinterpret_cast<const uint64_t*>(in + (uint64_t)lane * 8);  // HW handles misalignment
+    if (nchunks) x_next = *reinterpret_cast<const uint64_t*>(in + min((uint64_t)lane, last_chunk) * 8);  // HW handles misalignment
+    if ((uint64_t)lane >= nchunks) x_next = 0;
     for (uint64_t t0 = 0; t0 < nchunks; t0 += kWave) {
         const uint64_t c = t0 + lane;
         const bool valid = c < nchunks;
         const uint64_t x = x_next;
-        x_next = 0;
-        if (c + kWave < nchunks) x_next = *reinterpret_cast<const uint64_t*>(in + (c + kWave) * 8);
+        x_next = *reinterpret_cast<const uint64_t*>(in + min(c + kWave, last_chunk) * 8);
+        if (c + kWave >= nchunks) x_next = 0;
         const uint32_t nvalid = (uint32_t)min((uint64_t)kWave, nchunks - t0);
         {   // adler partials: weight of byte j of this chunk is len - (c*8 + j)
             uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
