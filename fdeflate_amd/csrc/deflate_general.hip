@@ -889,6 +889,10 @@ __device__ __forceinline__ void g_append(uint64_t& v0, uint64_t& v1, uint32_t& n
 // Every lane takes four consecutive positions per step (256 per wavefront): back-references are at
 // least four bytes long, so a lane sees at most one or two of them and its codes stay below the
 // 118 bits one ring update takes.
+// The loads of the walk (the next step's four bytes, the next chunk's records) are UNCONDITIONAL,
+// from clamped addresses: behind a load in a branch the compiler has to wait for every load in
+// flight at the join, the prefetch it has just issued included.  (`in` has at least four readable
+// bytes: the kernel stands a padded copy in for a shorter stream.)
 template <bool EMIT>
 __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMatchRec* recs, uint32_t b0, uint32_t b1,
                        uint32_t m0, uint32_t m1, uint64_t len, uint64_t& acc_a, uint64_t& acc_b) {
@@ -896,30 +900,31 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
     constexpr uint32_t kStep = 4 * kWave;
     for (uint32_t i = lane; i < kGChunk; i += kWave) lds.marks[i] = 0;  // (shared with the Huffman scratch)
     wave_sync();
-    // the four bytes at p, read as one dword where the stream has them (never past its end)
+    // the four bytes at p (zero behind the block / the stream), never reading past the stream's end
+    const uint32_t last4 = len >= 4 ? (uint32_t)len - 4 : 0u;
     auto load4 = [&](uint32_t p) -> uint32_t {
-        if (p >= b1) return 0u;
-        if ((uint64_t)p + 4 <= len) {
-            uint32_t w;
-            __builtin_memcpy(&w, in + p, 4);
-            return w;
-        }
-        uint32_t w = 0;
-        for (uint32_t j = 0; (uint64_t)p + j < len; j++) w |= (uint32_t)in[p + j] << (8 * j);
-        return w;
+        const uint32_t q = min(p, last4);
+        uint32_t w;
+        __builtin_memcpy(&w, in + q, 4);
+        const uint32_t sh = 8 * (p - q);  // the dword that ends at the stream's end, shifted down to p
+        w = sh < 32 ? w >> sh : 0u;
+        return p < b1 ? w : 0u;
     };
+    const uint32_t mlast = m1 ? m1 - 1 : 0;  // (the slice has at least two records, used or not)
     uint32_t mc = m0, covered = b0;  // next record to mark; end of the last back-reference so far
     uint32_t word_next = load4(b0 + 4 * lane);
+    GMatchRec rnext = recs[min(mc + lane, mlast)];
     for (uint32_t c0 = b0; c0 < b1; c0 += kGChunk) {
         const uint32_t cend = min(c0 + kGChunk, b1);
         for (;;) {
             const uint32_t idx = mc + lane;
-            GMatchRec r{0xFFFFFFFFu, 0};
-            if (idx < m1) r = recs[idx];
+            GMatchRec r = rnext;
+            if (idx >= m1) r.start = 0xFFFFFFFFu;
             const bool here = r.start < cend;
             if (here) lds.marks[r.start - c0] = r.info;
             const uint32_t cnt = (uint32_t)__popcll(__ballot(here));
             mc += cnt;
+            rnext = recs[min(mc + lane, mlast)];  // for the next round, or for the next chunk (four steps away)
             if (cnt < (uint32_t)kWave) break;
         }
         wave_sync();
@@ -1007,6 +1012,15 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
     }
     const GMatchRec* recs = a.matches + g_match_slice(off - in0, sid);
     const GBlockRec* blks = a.blocks + g_block_slice(off - in0, sid);
+    if (len < 4) {
+        // The walks read dwords.  A stream this short has no back-references, so its slice of the
+        // record array (two records at least) is free: a zero-padded copy of the bytes goes there.
+        uint8_t* pad = reinterpret_cast<uint8_t*>(const_cast<GMatchRec*>(recs));
+        if (lane < 8) pad[lane] = (uint64_t)lane < len ? in[lane] : (uint8_t)0;
+        __threadfence();
+        __builtin_amdgcn_wave_barrier();
+        in = pad;
+    }
     for (int i = lane; i < kGRingDw; i += kWave) lds.ring[i] = 0;
     if (lane < 30) lds.dmeta[lane] = (uint32_t)kDistBase[lane] | ((uint32_t)kDistExtra[lane] << 16);
     wave_sync();
