@@ -762,32 +762,49 @@ def test_png_filters_bit_exact_and_fused_decode(harness):
                 os.environ.pop(name, None)
             else:
                 os.environ[name] = val
-    # error statuses
-    bad = [bytes([7, 1, 2, 3]), bytes([0, 1, 2])]
-    bbuf, boff = streams.pack_exact(bad)
-    oo = torch.from_numpy(np.array([0, 8, 16], dtype=np.int64)).cuda()
-    st = fd.png_unfilter_batch(torch.from_numpy(bbuf).cuda(), torch.from_numpy(boff.astype(np.int64)).cuda(),
-                               torch.zeros(16, dtype=torch.uint8, device="cuda"), oo, 3, 1)
-    assert st.cpu().tolist() == [1, 2]
-    # fused: 64 x 1023-byte rows with a filter byte each (the bench's buffers), RGB8, plus one broken stream
-    from fdeflate_amd import synth
-    n, rows, rb, bpp = 96, 64, 1023, 3
-    filt_imgs = [synth.gen_stream_np(i, rows * (rb + 1)).tobytes() for i in range(n)]   # type byte 0..4 per row
-    comps = [ob.compress_ultra_fast(f) for f in filt_imgs]
-    comps[5] = comps[5][:-9]
-    cbuf, coff = streams.pack_exact(comps)
-    foff = np.arange(n + 1, dtype=np.int64) * (rows * (rb + 1))
-    poff = np.arange(n + 1, dtype=np.int64) * (rows * rb)
-    d_f = torch.zeros(int(foff[-1]), dtype=torch.uint8, device="cuda")
-    d_p = torch.zeros(int(poff[-1]), dtype=torch.uint8, device="cuda")
-    out_len, status, adler, pst = fd.inflate_png_batch(torch.from_numpy(cbuf).cuda(), torch.from_numpy(coff.astype(np.int64)).cuda(),
-                                                       d_f, torch.from_numpy(foff).cuda(), d_p, torch.from_numpy(poff).cuda(), rb, bpp)
-    torch.cuda.synchronize()
-    stl, psl, hp = status.cpu().tolist(), pst.cpu().tolist(), d_p.cpu().numpy()
-    for i in range(n):
-        if i == 5:
-            assert stl[i] == 2 and psl[i] == 3
-            continue
-        est, epix = ob.png_unfilter(filt_imgs[i], rb, bpp)
-        assert stl[i] == 0 and psl[i] == est == 0
-        assert hp[poff[i]:poff[i + 1]].tobytes() == epix, i
+    # error statuses and the fused call, with one image per wavefront and with several (an image
+    # with a bad filter type, a bad size or a failed decode shares its wavefront with good ones)
+    old3 = os.environ.get("FDH_PNG_IMAGES_PER_WAVE")
+    try:
+        for per_wave in ("1", "4", "8"):
+            os.environ["FDH_PNG_IMAGES_PER_WAVE"] = per_wave
+            # error statuses
+            good = ob.png_filter(bytes(range(9)), 3, 1, bytes([1, 2, 4]))[1]
+            bad = [good, bytes([7, 1, 2, 3]), bytes([0, 1, 2]), good, b"", good]
+            bbuf, boff = streams.pack_exact(bad)
+            oo = torch.from_numpy(np.arange(7, dtype=np.int64) * 16).cuda()
+            pix_out = torch.full((96,), 0xEE, dtype=torch.uint8, device="cuda")
+            st = fd.png_unfilter_batch(torch.from_numpy(bbuf).cuda(), torch.from_numpy(boff.astype(np.int64)).cuda(),
+                                       pix_out, oo, 3, 1)
+            assert st.cpu().tolist() == [0, 1, 2, 0, 0, 0]
+            h = pix_out.cpu().numpy()
+            for k in (0, 3, 5):
+                assert h[16 * k:16 * k + 9].tobytes() == bytes(range(9)) and np.all(h[16 * k + 9:16 * k + 16] == 0xEE)
+            assert np.all(h[16:48] == 0xEE) and np.all(h[64:80] == 0xEE)   # nothing written for the bad / empty ones
+            # fused: 64 x 1023-byte rows with a filter byte each (the bench's buffers), RGB8, plus one broken stream
+            from fdeflate_amd import synth
+            n, rows, rb, bpp = 96, 64, 1023, 3
+            filt_imgs = [synth.gen_stream_np(i, rows * (rb + 1)).tobytes() for i in range(n)]   # type byte 0..4 per row
+            comps = [ob.compress_ultra_fast(f) for f in filt_imgs]
+            comps[5] = comps[5][:-9]
+            cbuf, coff = streams.pack_exact(comps)
+            foff = np.arange(n + 1, dtype=np.int64) * (rows * (rb + 1))
+            poff = np.arange(n + 1, dtype=np.int64) * (rows * rb)
+            d_f = torch.zeros(int(foff[-1]), dtype=torch.uint8, device="cuda")
+            d_p = torch.zeros(int(poff[-1]), dtype=torch.uint8, device="cuda")
+            out_len, status, adler, pst = fd.inflate_png_batch(torch.from_numpy(cbuf).cuda(), torch.from_numpy(coff.astype(np.int64)).cuda(),
+                                                               d_f, torch.from_numpy(foff).cuda(), d_p, torch.from_numpy(poff).cuda(), rb, bpp)
+            torch.cuda.synchronize()
+            stl, psl, hp = status.cpu().tolist(), pst.cpu().tolist(), d_p.cpu().numpy()
+            for i in range(n):
+                if i == 5:
+                    assert stl[i] == 2 and psl[i] == 3
+                    continue
+                est, epix = ob.png_unfilter(filt_imgs[i], rb, bpp)
+                assert stl[i] == 0 and psl[i] == est == 0
+                assert hp[poff[i]:poff[i + 1]].tobytes() == epix, i
+    finally:
+        if old3 is None:
+            os.environ.pop("FDH_PNG_IMAGES_PER_WAVE", None)
+        else:
+            os.environ["FDH_PNG_IMAGES_PER_WAVE"] = old3
