@@ -333,7 +333,6 @@ constexpr int kSlot = 2;  // 16-byte chunks per line slot (32 bytes): 12 KiB of 
 struct PngPipeLds {
     uint4 lin[kWave][2][kSlot];
     uint4 lout[kWave][2][kSlot];
-    uint4 rowbuf[kPipeMaxChunks];
     uint64_t sbase[kPipeMaxImages + 1], dbase[kPipeMaxImages];  // offsets of the images' buffers (sbase[j + 1]: end of j's)
     uint32_t rowsum[kPipeMaxImages + 1];
     uint32_t bad[kPipeMaxImages];  // first row with a bad filter type, per image
@@ -351,6 +350,7 @@ struct PngPipeRow {  // one row of the sequence, as a lane sees it
 template <int BPP>
 __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per_wave) {
     __shared__ PngPipeLds lds;
+    extern __shared__ uint4 png_rowbuf[];  // lane 63 -> lane 0: one row of chunks (sized by the launch)
     const uint32_t lane = threadIdx.x;
     const uint64_t img0 = (uint64_t)blockIdx.x * per_wave;
     const uint32_t cnt = (uint32_t)min((uint64_t)per_wave, a.n - img0);
@@ -501,11 +501,11 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
         uint4 u = make_uint4(png_from_lane_below(last.x), png_from_lane_below(last.y), png_from_lane_below(last.z), png_from_lane_below(last.w));
         if (on) {
             const uint4 f = lds.lin[lane][par][cu & (kSlot - 1)];
-            if (lane == 0) u = lds.rowbuf[cu];
+            if (lane == 0) u = png_rowbuf[cu];
             if (cur.r == 0) u = make_uint4(0, 0, 0, 0);
             last = png_chunk<BPP, true>(f, u, la, ua, m);
             lds.lout[lane][par][cu & (kSlot - 1)] = last;
-            if (lane == kWave - 1) lds.rowbuf[cu] = last;
+            if (lane == kWave - 1) png_rowbuf[cu] = last;
         }
         c++;
     }
@@ -530,6 +530,7 @@ static int png_launch(const fdh::PngArgs& a, uint32_t bpp, hipStream_t stream) {
         const int v = atoi(e3);
         if (v >= 1 && v <= (int)fdh::kPipeMaxImages) per_wave = (uint32_t)v;
     }
+    const size_t rowbuf_bytes = (size_t)((a.row_bytes + 15) / 16) * 16;
     const dim3 block(fdh::kWave);
     const dim3 grid(per_lane ? (unsigned)((a.n + fdh::kWave - 1) / fdh::kWave) : pipe ? (unsigned)((a.n + per_wave - 1) / per_wave) : (unsigned)a.n);
 #define FDH_PNG_CASE(B)                                                                                  \
@@ -537,7 +538,7 @@ static int png_launch(const fdh::PngArgs& a, uint32_t bpp, hipStream_t stream) {
         if (per_lane)                                                                                    \
             hipLaunchKernelGGL((fdh::png_filter_kernel<B, UNFILTER>), grid, block, 0, stream, a);        \
         else if (pipe)                                                                                   \
-            hipLaunchKernelGGL((fdh::png_pipe_kernel<B>), grid, block, 0, stream, a, per_wave);          \
+            hipLaunchKernelGGL((fdh::png_pipe_kernel<B>), grid, block, rowbuf_bytes, stream, a, per_wave); \
         else                                                                                             \
             hipLaunchKernelGGL((fdh::png_wave_kernel<B, UNFILTER>), grid, block, 0, stream, a);          \
         break;
