@@ -219,10 +219,13 @@ struct SegReader {
         gp = addr - mis;
         in_wr = in_rd = 0;
         has_a = has_b = false;
-        for (int k = 0; k < kSegInWords / kSegChunk; k++) {
-            put(seg_load(gp, buf_lo, buf_hi));
-            gp += 4 * kSegChunk;
-        }
+        // all the chunks are requested before the first one is used: one trip to memory, not four
+        SegChunk c[kSegInWords / kSegChunk];
+#pragma unroll
+        for (int k = 0; k < kSegInWords / kSegChunk; k++) c[k] = seg_load(gp + 4 * kSegChunk * k, buf_lo, buf_hi);
+#pragma unroll
+        for (int k = 0; k < kSegInWords / kSegChunk; k++) put(c[k]);
+        gp += 4 * kSegInWords;
         in_rd = mis >> 2;
         lo = ring[seg_slot(lane_off, in_rd)];
         hi = ring[seg_slot(lane_off, in_rd + 1)];
@@ -241,10 +244,16 @@ struct SegReader {
             }
         }
         has_a = has_b = false;
-        while ((uint32_t)kSegInWords - (in_wr - in_rd) >= (uint32_t)kSegChunk) {
-            put(seg_load(gp, buf_lo, buf_hi));
-            gp += 4 * kSegChunk;
-        }
+        // (again: the chunks that fit are requested together, then written to the ring)
+        const uint32_t want = ((uint32_t)kSegInWords - (in_wr - in_rd)) / (uint32_t)kSegChunk;
+        SegChunk c[kSegInWords / kSegChunk];
+#pragma unroll
+        for (int k = 0; k < kSegInWords / kSegChunk; k++)
+            if ((uint32_t)k < want) c[k] = seg_load(gp + 4 * kSegChunk * k, buf_lo, buf_hi);
+#pragma unroll
+        for (int k = 0; k < kSegInWords / kSegChunk; k++)
+            if ((uint32_t)k < want) put(c[k]);
+        gp += 4 * kSegChunk * want;
     }
     __device__ __forceinline__ uint32_t level() const { return in_wr - in_rd; }  // dwords past lo/hi
     __device__ __forceinline__ bool starved() const { return in_rd > in_wr; }
