@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
 }
 
 // Fast general kernel: the same decoder with a 10-bit literal/length table (4 KiB instead of 16 KiB:
-// 16.7 KiB of LDS per stream, 9 workgroups per CU instead of 5 -- the tile decoder is latency-bound,
-// so occupancy is throughput).  Codes longer than 10 bits are resolved by the canonical walk.  Its
+// 13.8 KiB of LDS per stream with the 2 KiB output ring, 11 workgroups per CU instead of 5 -- the
+// tile decoder is latency-bound, so occupancy is throughput).  Codes longer than 10 bits are resolved by the canonical walk.  Its
 // double-literal pairing is not the reference's, so every result that needs the exact serial
 // decoder is left PENDING_SERIAL for inflate_general_kernel.
 constexpr int kFastLitBits = 10;
