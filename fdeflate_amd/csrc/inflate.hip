@@ -19,6 +19,7 @@
 // by the symbol-serial decoder, whose pairing is the reference's (DESIGN.md "error parity").
 #include <algorithm>
 #include <mutex>
+#include <cstddef>
 #include "inflate_stream.h"
 #include "inflate_lanes.h"
 #include "inflate_segments.h"
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
 }
 
 // Fast general kernel: the same decoder with a 10-bit literal/length table (4 KiB instead of 16 KiB:
-// 13.8 KiB of LDS per stream with the 2 KiB output ring, 11 workgroups per CU instead of 5 -- the
+// 12.6 KiB of LDS per stream with the 2 KiB output ring, 12 workgroups per CU instead of 5 -- the
 // tile decoder is latency-bound, so occupancy is throughput).  Codes longer than 10 bits are resolved by the canonical walk.  Its
 // double-literal pairing is not the reference's, so every result that needs the exact serial
 // decoder is left PENDING_SERIAL for inflate_general_kernel.
@@ -159,11 +160,14 @@ constexpr int kFastLitBits = 10;
 #ifndef FDH_FAST_WAVES_PER_SIMD
 #define FDH_FAST_WAVES_PER_SIMD 2
 #endif
-struct GeneralFastLds {  // (no span decoder in this kernel: it would cost LDS for its rings)
+// (No span decoder in this kernel: it would cost LDS for its rings.  The scratch of the block-header
+// parser lies over the tiles' match list: a header is parsed between tiles, never during one.)
+struct GeneralFastLds {
     TableSetT<kFastLitBits> tables;
     WaveIo io;
-    HeaderScratch hs;
 };
+static_assert(sizeof(HeaderScratch) <= sizeof(WaveIo::mlist) && offsetof(WaveIo, mlist) % 16 == 0,
+              "the header scratch must fit the match list it shares LDS with");
 __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_general_fast_kernel(InflateBatchArgs a) {
     __shared__ GeneralFastLds lds;
     const int lane = threadIdx.x;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_genera
     if (sid >= a.n) return;
     if (a.only_pending && a.status[sid] != kPending) return;
     const StreamArgs s = stream_args(a, sid);
-    InflaterT<kFastLitBits, false> inf(lds.tables, lds.io, &lds.hs, lane);
+    InflaterT<kFastLitBits, false> inf(lds.tables, lds.io, reinterpret_cast<HeaderScratch*>(lds.io.mlist), lane);
     inf.init(s);
     const StreamResult r = inf.run<true, false>();
     if (lane == 0) {
