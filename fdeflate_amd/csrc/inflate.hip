@@ -151,14 +151,16 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
     }
 }
 
-// Fast general kernel: the same decoder with a 10-bit literal/length table (4 KiB instead of 16 KiB:
-// 12.6 KiB of LDS per stream with the 2 KiB output ring, 12 workgroups per CU instead of 5 -- the
-// tile decoder is latency-bound, so occupancy is throughput).  Codes longer than 10 bits are resolved by the canonical walk.  Its
+// Fast general kernel: the same decoder with an 8-bit literal/length table (1 KiB instead of 16 KiB)
+// and at most 128 VGPRs (20 of them spilled): 9.9 KiB of LDS per stream with the 2 KiB output ring,
+// 16 workgroups per CU instead of 5 -- the tile decoder is latency-bound, so occupancy is
+// throughput (10 bits / 159 VGPRs / 9 per CU: 33 GB/s on zlib-6 streams; 12 per CU: 40; 9 bits and
+// 14 per CU: 45; this: 49).  Codes longer than 8 bits are resolved by the canonical walk.  Its
 // double-literal pairing is not the reference's, so every result that needs the exact serial
 // decoder is left PENDING_SERIAL for inflate_general_kernel.
-constexpr int kFastLitBits = 10;
+constexpr int kFastLitBits = 8;
 #ifndef FDH_FAST_WAVES_PER_SIMD
-#define FDH_FAST_WAVES_PER_SIMD 2
+#define FDH_FAST_WAVES_PER_SIMD 4
 #endif
 // (No span decoder in this kernel: it would cost LDS for its rings.  The scratch of the block-header
 // parser lies over the tiles' match list: a header is parsed between tiles, never during one.)
