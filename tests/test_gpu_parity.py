@@ -652,6 +652,39 @@ def test_general_encoder_level1_and_rle_bit_exact(harness):
             os.environ["FDH_GEN_LANES"] = old
 
 
+def test_general_encoder_roundtrip_at_scale(harness):
+    """8192 x 64 KiB through the level-1 and the RLE encoder on the GPU, decoded again on the GPU by
+    the general kernels (dynamic blocks, real distances): every stream Ok, lengths exact, decoded ==
+    raw, reported Adler-32 == the trailer the encoder wrote; the oracle byte-compares a strided
+    sample of the compressed streams."""
+    import torch
+    import fdeflate_amd as fd
+    from fdeflate_amd import synth
+    n, L = 8192, 65536
+    raw = synth.gen_batch_torch(40000, n, L)
+    bound = (fd.compress_bound(L) + 15) & ~15
+    in_off = torch.arange(n + 1, dtype=torch.int64, device="cuda") * L
+    c_off = torch.arange(n + 1, dtype=torch.int64, device="cuda") * bound
+    for mode, enc in ((fd.MODE_LEVEL1, ob.compress_level1), (fd.MODE_RLE, ob.compress_rle)):
+        comp = torch.zeros(n * bound, dtype=torch.uint8, device="cuda")
+        clen = fd.deflate_general_batch(raw.view(-1), in_off, comp, c_off, mode)
+        clen_h = clen.cpu().numpy().view(np.uint32)
+        assert int(clen_h.max()) <= bound
+        for i in range(0, n, 997):
+            exp = enc(raw[i].cpu().numpy().tobytes())
+            got = comp[i * bound:i * bound + int(clen_h[i])].cpu().numpy().tobytes()
+            assert got == exp, (mode, i)
+        out = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+        out_len, status, adler = fd.inflate_batch(comp, c_off, out, in_off)
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0 and bool((out_len == L).all()) and torch.equal(out, raw.view(-1)), mode
+        idx = (c_off[:-1] + clen.to(torch.int64))[:, None] + torch.arange(-4, 0, device="cuda")[None, :]
+        tr = comp[idx].to(torch.int64)
+        trailer = (tr[:, 0] << 24) | (tr[:, 1] << 16) | (tr[:, 2] << 8) | tr[:, 3]
+        assert torch.equal(trailer, adler.to(torch.int64) & 0xFFFFFFFF), mode
+        del comp, out
+
+
 def test_multi_gpu_entry_points_every_visible_device(harness):
     """fdh_init / fdh_inflate_batch_multi / fdh_shutdown: the mixed batch sharded by contiguous
     ranges over every visible GPU from ONE process, results all-gathered (RCCL when more than one
