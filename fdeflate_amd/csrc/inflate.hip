@@ -23,6 +23,7 @@
 #include "inflate_stream.h"
 #include "inflate_lanes.h"
 #include "inflate_segments.h"
+#include "inflate_seg2.h"
 
 namespace fdh {
 
@@ -301,6 +302,10 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
             const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;
             if (lane == leader) next = atomicAdd(&a.list[1], 1u);
             next = uni(next);
+            if (a.src_list) {  // only what the kernel in front left over
+                if (next >= a.src_list[0]) break;
+                next = uni(a.src_list[4 + next]);
+            }
             if (next >= a.n) break;
 #ifdef FDH_DEBUG_TILES
             // diagnostics of the stream hand-out: how often was each stream handed out, and was every
@@ -312,6 +317,27 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
         }
     } else {
         segments_decode(a, lds, (uint64_t)blockIdx.x * kSegWaves + threadIdx.x / kWave);
+    }
+}
+
+// Canonical streams, counted by segments and written by intervals (inflate_seg2.h): one stream per
+// wavefront, one workgroup of 16 persistent wavefronts per CU with all of its LDS.
+__global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArgs a) {
+    __shared__ Seg2Lds lds;
+    // the hand-scheduled loops address the table from LDS offset 0 (`raw & 0x3ffc` IS the address)
+    if (lds_offset(lds.lit) != 0) __builtin_trap();
+    for (int i = threadIdx.x; i < kLitSize; i += kS2Waves * kWave) lds.lit[i] = seg2_entry_build(a.canon_lit, (uint32_t)i);
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    uint2* const ckpt = a.ckpt + (size_t)(blockIdx.x * kS2Waves + threadIdx.x / kWave) * kS2CkptPerWave;
+    for (;;) {
+        // the first ACTIVE lane fetches (see inflate_segments_kernel)
+        uint32_t next = 0;
+        const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;
+        if (lane == leader) next = atomicAdd(&a.list[2], 1u);
+        next = uni(next);
+        if (next >= a.n) break;
+        seg2_decode(a, lds, ckpt, next);
     }
 }
 
@@ -424,6 +450,19 @@ extern "C" int fdh_debug_read(uint32_t* host, uint32_t nwords, int reset) {
 }
 #endif
 
+#ifdef FDH_S2_DEBUG
+extern "C" int fdh_debug_s2(uint32_t* host, uint32_t sid) {  // returns the records of the last run, then arms for `sid`
+    hipDeviceSynchronize();
+    uint32_t nrec = 0;
+    hipMemcpyFromSymbol(&nrec, HIP_SYMBOL(fdh::g_s2dbg_n), 4);
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_s2dbg), 8 * 2048 * 4);
+    uint32_t z = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_s2dbg_n), &z, 4);
+    hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_s2dbg_sid), &sid, 4);
+    return (int)nrec;
+}
+#endif
+
 // device address of g_canon, looked up once per device by fdh_launch_canon_build (the lookup
 // synchronises, so it must stay off the launch path)
 static fdh::CanonTables* g_canon_dev[64] = {};
@@ -486,31 +525,48 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         if (e != hipSuccess) return (int)e;
         fdh::CanonTables* canon = (ordinal >= 0 && ordinal < 64) ? g_canon_dev[ordinal] : nullptr;
         if (!canon) return (int)hipErrorNotInitialized;
-        // stream-ordered scratch for the compacted list of leftovers (no host synchronisation)
+        // stream-ordered scratch (no host synchronisation): two compacted lists of leftovers (what the
+        // interval kernel leaves to the segment kernel, what that one leaves to the kernels behind) and
+        // the interval kernel's checkpoints
         uint32_t* list = nullptr;
-        if (hipMallocAsync(reinterpret_cast<void**>(&list), (n + 4) * sizeof(uint32_t), stream) != hipSuccess) {
+        int cus;
+        {
+            std::lock_guard<std::mutex> lock(g_dev_mutex);
+            if (g_cu_count[ordinal & 63] == 0) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ordinal) != hipSuccess || v <= 0) v = 256;
+                g_cu_count[ordinal & 63] = v;
+            }
+            cus = g_cu_count[ordinal & 63];
+        }
+        const bool seg2 = !(flags & 0x400u);
+        const unsigned s2blocks = std::min((unsigned)((n + fdh::kS2Waves - 1) / fdh::kS2Waves), (unsigned)cus);
+        const size_t list_words = 2 * (size_t)(n + 4);
+        const size_t ckpt_bytes = seg2 ? (size_t)s2blocks * fdh::kS2Waves * fdh::kS2CkptPerWave * sizeof(uint2) : 0;
+        if (hipMallocAsync(reinterpret_cast<void**>(&list), list_words * sizeof(uint32_t) + ckpt_bytes, stream) != hipSuccess) {
             (void)hipGetLastError();
             list = nullptr;  // fall back to the status-scan form
         } else {
             e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
+            if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 4 * sizeof(uint32_t), stream);
             if (e != hipSuccess) return (int)e;
         }
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->len4, canon->hdr,
-                        fdh::kCanonBits, fdh::kPending, list};
-        unsigned sblocks = (unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves);
-        if (list) {  // persistent wavefronts: two workgroups (80 KiB of LDS each) per CU
-            int cus;
-            {
-                std::lock_guard<std::mutex> lock(g_dev_mutex);
-                if (g_cu_count[ordinal & 63] == 0) {
-                    int v = 0;
-                    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ordinal) != hipSuccess || v <= 0) v = 256;
-                    g_cu_count[ordinal & 63] = v;
-                }
-                cus = g_cu_count[ordinal & 63];
+                        fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr};
+        if (list && seg2) {  // interval kernel first; what it leaves goes through the segment kernel
+            sa.ckpt = reinterpret_cast<uint2*>(list + list_words);
+            hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
+            e = hipGetLastError();
+            if (e != hipSuccess) return (int)e;
+            sa.src_list = list;
+            sa.list = list + (n + 4);
+            if (flags & 0x800u) {  // debug: the interval kernel only
+                (void)hipFreeAsync(list, stream);
+                return 0;
             }
-            sblocks = std::min(sblocks, (unsigned)(2 * cus));
         }
+        unsigned sblocks = (unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves);
+        if (list) sblocks = std::min(sblocks, (unsigned)(2 * cus));  // persistent wavefronts: two workgroups (80 KiB of LDS each) per CU
         hipLaunchKernelGGL(fdh::inflate_segments_kernel, dim3(sblocks), dim3(fdh::kSegWaves * fdh::kWave), 0, stream, sa);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
@@ -520,7 +576,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             return 0;
         }
         if (list) {
-            a.list = list;
+            a.list = sa.list;
             unsigned cblocks = (unsigned)((n + fdh::kCanonWaves - 1) / fdh::kCanonWaves);
             hipLaunchKernelGGL(fdh::inflate_canon_kernel, dim3(cblocks), dim3(fdh::kCanonWaves * fdh::kWave), 0, stream, a);
             e = hipGetLastError();

@@ -1,0 +1,854 @@
+// inflate_seg2.h -- interval decoder: one ultra-fast-format stream per wavefront, counted by
+// segments, written by intervals.
+//
+// A stream that starts with the ultra-fast encoder's fixed prefix (reference
+// src/compress/ultrafast.rs:82-88) is one final dynamic block with a known table; the inner loop is
+// the reference's (src/decompress.rs:645-830: table look-up, literals, dist-1 run).
+//
+//   counting pass   as in inflate_segments.h: the block data is cut into up to 64 equal bit ranges,
+//           one per lane; a lane walks a GUESSED chain from the first bit of its range through a
+//           synchronisation window (x0 = where it leaves it), counts from there to the end of the
+//           range, then takes its real start from its left neighbour's end, counts the real chain
+//           through the window and must land exactly on x0 (by induction from lane 0 every counted
+//           chain is then the real one; a lane that lands elsewhere re-counts).  New: while it
+//           counts, a lane leaves a CHECKPOINT (bit position, bytes so far, bulk lines so far) in a
+//           per-wavefront scratch in global memory every kS2Meter look-ups, which cuts its chain into
+//           INTERVALS of at most four groups of look-ups.
+//   writing pass    the intervals of all lanes form one list in output order.  A round takes the
+//           next <= 64 of them, one per lane: the stream bytes they cover are loaded ONCE, coalesced,
+//           into a flat LDS image; the output bytes they produce are OR-ed into a zero-initialised
+//           LDS image of the output and leave it as whole, coalesced 16-B pieces (128-B lines) with
+//           the Adler-32 folded in on the way.  No per-lane rings, no per-lane stores, nothing of
+//           the stream is fetched twice by this pass.
+//           Every lane simply runs four groups of 8 look-ups from its checkpoint: a lane whose
+//           interval ends earlier decodes on into the next interval -- what it ORs there are the
+//           bytes the next lane ORs to the same places (inflate_seg2_groups.h).
+//           A run (src/decompress.rs:793-801) is not decoded into the image by its lane: the
+//           wavefront fills it from the byte in front of it; of a run chain of >= kS2LongRun bytes
+//           only 16..31 bytes pass through the image, the whole 16-B lines in between ("bulk") are
+//           stored to global memory directly and their Adler-32 term has a closed form.  Image
+//           positions are output positions minus the bulk bytes in front of them, so a piece of the
+//           image is a piece of the output and every interval fits the image.
+//
+// Anything unusual -- not canonical, a bad / truncated token, a full slot, too many checkpoints, a
+// checksum mismatch -- leaves the stream PENDING for the kernels behind (inflate.hip).
+#pragma once
+#include "inflate_segments.h"
+#include "inflate_seg2_groups.h"
+
+namespace fdh {
+
+constexpr int kS2Waves = 16;               // wavefronts (= streams in flight) per workgroup, one workgroup per CU
+constexpr uint32_t kS2AWords = 1024;       // per wavefront: input ring of the counting pass / input image (4 KiB, 4 KiB aligned)
+constexpr uint32_t kS2BWords = 1280;       // per wavefront: output image (5 KiB)
+constexpr uint32_t kS2InCap = 3584;        // bytes of the input image
+constexpr uint32_t kS2OutCap = kS2BWords * 4;
+constexpr uint32_t kS2Pairs = 4;           // pairs of look-ups per group
+constexpr uint32_t kS2Meter = 32;          // look-ups per interval (four groups of the writing pass)
+constexpr uint32_t kS2RunCost = 8;         // what a run chain costs on the meter: the half it ends
+constexpr int kS2Repeat = 8;               // run tokens merged into one chain
+constexpr uint32_t kS2LongRun = 64;        // a chain at least this long leaves whole lines out of the image
+// Input bytes a lane can touch from the byte of its first bit in one round: 4 x (a group of 96 bits +
+// a chain of 8 x 18 bits) = 120 B, the 8-B window, the prefetched dword and the 3 bytes in front.
+constexpr uint32_t kS2InReach = 144;
+// Output bytes a lane can OR behind the end of its interval: 4 groups x 24 B of literals + its last dword.
+constexpr uint32_t kS2OutReach = 104;
+constexpr uint32_t kS2HeadSlots = 6;       // checkpoint slots of the chain through the window (start .. end)
+constexpr uint32_t kS2Slots = 48;          // checkpoint slots per lane
+constexpr uint32_t kS2CkptPerWave = kS2Slots * kWave;  // uint2 entries of scratch per wavefront
+constexpr uint32_t kS2PosBits = 17;        // checkpoint: segment-relative bit position below 2^17, bulk lines below 2^15
+constexpr uint32_t kS2MaxBreaks = 64;
+
+#ifdef FDH_S2_DEBUG
+__device__ uint32_t g_s2dbg[8 * 2048];
+__device__ uint32_t g_s2dbg_n;
+__device__ uint32_t g_s2dbg_sid = 0xFFFFFFFFu;
+#define S2DBG(tag, a0, a1, a2, a3, a4, a5, a6)                                                     \
+    do {                                                                                           \
+        if ((uint32_t)sid == g_s2dbg_sid && lane == 0) {                                           \
+            const uint32_t i_ = atomicAdd(&g_s2dbg_n, 1u);                                         \
+            if (i_ < 2048) {                                                                       \
+                uint32_t* r_ = g_s2dbg + 8 * i_;                                                   \
+                r_[0] = (tag); r_[1] = (a0); r_[2] = (a1); r_[3] = (a2); r_[4] = (a3);             \
+                r_[5] = (a4); r_[6] = (a5); r_[7] = (a6);                                          \
+            }                                                                                      \
+        }                                                                                          \
+    } while (0)
+#else
+#define S2DBG(tag, a0, a1, a2, a3, a4, a5, a6) do { } while (0)
+#endif
+
+struct Seg2Lds {
+    uint32_t lit[kLitSize];
+    uint32_t a[kS2Waves * kS2AWords];
+    uint32_t b[kS2Waves * kS2BWords];
+};
+static_assert(sizeof(Seg2Lds) == 160 * 1024, "one workgroup owns the LDS of its CU");
+
+// One token in its general, select-only form (the step behind a group).  `raw` = 32 window bits,
+// the token starting at bit 2.  A literal step is read from the LDS table; for a zero entry the lanes
+// that `need` the token fetch it from the canonical table in global memory (device layout of
+// inflate_tables.h).  `single`: take the first literal of a literal step alone (its length comes from
+// `len4`, 256 x 4 bits in one VGPR, read with ds_bpermute).  Call with all lanes active.
+struct S2Tok {
+    uint32_t used;  // stream bits
+    uint32_t nlit;  // literals (0 for a run / end-of-block / impossible token)
+    uint32_t run;   // run length (0: not a run)
+    bool eob, bad;
+};
+__device__ __forceinline__ S2Tok s2_token(const uint32_t* lit, const uint32_t* canon, uint32_t len4, uint32_t raw, bool need,
+                                          bool single) {
+    const uint32_t w = raw >> 2;
+    const uint32_t idx = w & (kLitSize - 1);
+    const uint32_t e = lit[idx];
+    S2Tok t;
+    t.used = e & 15;
+    t.nlit = (e >> 6) & 3;
+    t.run = 0;
+    t.eob = t.bad = false;
+    const bool first_only = single && t.nlit > 1;
+    if (__any(need && first_only)) {
+        const uint32_t b1 = (e >> 8) & 0xFF;
+        const uint32_t ww = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b1 >> 3) << 2), (int)len4);
+        const uint32_t len1 = (ww >> ((b1 & 7) * 4)) & 15;
+        t.used = first_only ? len1 : t.used;
+        t.nlit = first_only ? 1u : t.nlit;
+    }
+    const bool other = need && e == 0;
+    if (__any(other)) {
+        uint32_t cl = K_LONG << 4;
+        if (other) cl = canon[idx];
+        const uint32_t kind = (cl >> 4) & 15, nb = cl & 15, ex = (cl >> 8) & 31, base = cl >> 16;
+        const bool is_run = other && kind == K_LEN;
+        const bool is_eob = other && kind == K_EOB;
+        t.run = is_run ? base + ((w >> nb) & ((1u << ex) - 1)) : 0u;
+        t.used = is_run ? nb + ex + 1 : (is_eob ? nb : t.used);
+        t.eob = is_eob;
+        // the prefix declares one distance code: '0' = distance 1; it is the run token's last bit
+        t.bad = other && !is_eob && (!is_run || ((w >> (nb + ex)) & 1) != 0);
+    }
+    return t;
+}
+
+// State of one lane's counting scan.
+struct S2Scan {
+    uint32_t pos;   // segment-relative bit position of the next token
+    uint32_t cnt;   // output bytes counted
+    uint32_t bl;    // bulk lines among them (16 B each)
+    uint32_t stop;  // 0 none, 1 end-of-block (pos = its start, eob_bits its length), 2 fault
+    uint32_t eob_bits;
+};
+// Checkpoints of one lane: column `lane` of the wavefront's scratch, one uint2 per slot:
+// x = pos | bulk lines << 17, y = bytes - 16 x bulk lines (the image-space count).
+struct S2Ck {
+    uint2* col;
+    uint32_t slot;   // next slot to write
+    uint32_t last;   // last slot this scan may use for a cut (one more is kept for its end)
+    uint32_t m;      // look-ups since the last checkpoint
+};
+__device__ __forceinline__ void s2_ck_store(S2Ck& k, const S2Scan& s, bool doit) {
+    if (doit) {
+        k.col[k.slot * kWave] = make_uint2(s.pos | (s.bl << kS2PosBits), s.cnt - 16 * s.bl);
+        k.slot++;
+        k.m = 0;
+    }
+}
+// Before an action that costs `inc` look-ups: cut the interval here if it would not fit.
+__device__ __forceinline__ void s2_ck_meter(S2Ck& k, S2Scan& s, bool take, uint32_t inc) {
+    const bool cut = take && k.m + inc > kS2Meter;
+    const bool full = cut && k.slot >= k.last;
+    s.stop = full ? 2u : s.stop;  // out of slots: the stream is left to the other kernels
+    s2_ck_store(k, s, cut && !full);
+    k.m += take ? inc : 0u;
+}
+
+// A group of kS2Pairs pairs of look-ups on the lane's ring; returns the last entry looked up
+// (0: the lane sits on a token that is not a literal).
+__device__ __forceinline__ uint32_t s2_ring_group(uint32_t pairs, SegReader& rd, uint32_t rb, S2Scan& s) {
+    uint32_t c = rd.boff | (s.cnt << 6);
+    uint32_t ra = rb | ((rd.in_rd << 8) & 0xf00u);
+    const uint32_t ra0 = ra, b0 = rd.boff;
+    const uint32_t e = seg2_count_group(pairs, rb, rd.lo, rd.hi, c, ra);
+    const uint32_t words = ((ra - ra0) >> 8) & 15u;
+    rd.in_rd += words;
+    rd.boff = c & 63u;
+    s.cnt = c >> 6;
+    s.pos += 32 * words + rd.boff - b0;
+    return e;
+}
+
+// The general step of the counting scans: one token of any kind for the lanes in `take`; a run is
+// followed through the run tokens right behind it (a chain of at most kS2Repeat tokens, while
+// pos < end).  GUESS: nothing is counted, an impossible token or a stray end-of-block slides on by
+// one bit.  Otherwise the bytes are counted, the meter runs and a halt is recorded in s.stop.
+template <bool GUESS>
+__device__ __forceinline__ void s2_count_general(const uint32_t* lit, const uint32_t* canon, uint32_t len4, SegReader& rd,
+                                                 S2Scan& s, S2Ck& ck, bool take, bool single, uint32_t end, uint32_t limit) {
+    bool go = take;
+    uint32_t chain = 0;
+    for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
+        if (rep && __any(go && rd.level() < 2)) rd.refill_now();  // chains must not depend on what the ring happens to hold
+        const uint32_t raw = rd.raw_window();
+        const uint32_t nw = rd.peek();
+        S2Tok t = s2_token(lit, canon, len4, raw, go, single && rep == 0);
+        const bool accept = go && (rep == 0 || t.run != 0);
+        if (GUESS) {
+            const bool slide = accept && (t.bad || t.eob) && s.pos + 1 <= limit;
+            t.used = slide ? 1u : t.used;
+            t.nlit = slide ? 0u : t.nlit;
+            t.bad = slide ? false : t.bad;
+            t.eob = slide ? false : t.eob;
+        }
+        const bool fault = accept && (t.bad || s.pos + t.used > limit);
+        bool step = accept && !fault && !t.eob;
+        if (!GUESS && rep == 0) {
+            s2_ck_meter(ck, s, step, t.run ? kS2RunCost : 1u);
+            step = step && s.stop == 0;
+        }
+        const bool halt = accept && !step;
+        s.stop = (halt && s.stop == 0) ? (fault ? 2u : 1u) : s.stop;
+        s.eob_bits = (halt && t.eob) ? t.used : s.eob_bits;
+        if (!GUESS) s.cnt += (step && !t.run) ? t.nlit : 0u;
+        chain += step ? t.run : 0u;
+        const uint32_t adv = step ? t.used : 0u;
+        s.pos += adv;
+        rd.advance(adv, nw);
+        go = step && t.run != 0 && s.pos < end;
+    }
+    if (!GUESS) {
+        s.cnt += chain;
+        s.bl += chain >= kS2LongRun ? chain / 16 - 1 : 0u;
+    }
+}
+
+// Guessed chain through the window: from s.pos until pos >= window.  Nothing is counted.
+__device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const uint32_t* canon, SegReader& rd, uint32_t rb,
+                                              uint32_t limit, bool active, uint32_t window, S2Scan& s, S2Ck& ck) {
+    bool running = active && s.pos < window;
+    while (__any(running)) {
+        rd.events(running, kSegEventNeed);
+        for (int half = 0; half < 2; half++) {
+            const bool fast = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
+            bool general = running && !fast && rd.level() >= 2;
+            if (__any(fast)) {
+                if (fast) general = s2_ring_group(kS2Pairs, rd, rb, s) == 0;
+            }
+            if (__any(general)) s2_count_general<true>(lit, canon, 0u, rd, s, ck, general, false, window, limit);
+            running = running && s.stop == 0 && s.pos < window;
+        }
+    }
+}
+
+// The long loop of the counting pass: from s.pos until pos >= stop_at (the lane's range ends
+// somewhere inside a group: any symbol boundary will do for the neighbour), every byte counted.
+__device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const uint32_t* canon, SegReader& rd, uint32_t rb,
+                                             uint32_t limit, bool active, uint32_t stop_at, S2Scan& s, S2Ck& ck) {
+    bool running = active && s.stop == 0 && s.pos < stop_at;
+    if (running) rd.refill_now();
+    while (__any(running)) {
+        rd.events(running, kSegEventNeed);
+        for (int half = 0; half < 2; half++) {
+            bool fast = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
+            bool general = running && !fast && rd.level() >= 2;
+            if (__any(fast)) {
+                s2_ck_meter(ck, s, fast, 2 * kS2Pairs);
+                fast = fast && s.stop == 0;
+                if (fast) general = s2_ring_group(kS2Pairs, rd, rb, s) == 0;
+            }
+            if (__any(general)) s2_count_general<false>(lit, canon, 0u, rd, s, ck, general, false, stop_at, limit);
+            running = running && s.stop == 0 && s.pos < stop_at;
+        }
+    }
+}
+
+// The real chain through the window: from s.pos to x0, where it must land exactly.  Groups while
+// they cannot pass x0, then token by token, and one literal at a time once a whole step could pass
+// x0 (the guessed and the real chain may group literals differently).
+__device__ __forceinline__ void s2_head_scan(const uint32_t* lit, const uint32_t* canon, uint32_t len4, SegReader& rd,
+                                             uint32_t rb, uint32_t limit, bool active, uint32_t x0, S2Scan& s, S2Ck& ck) {
+    bool running = active && s.pos < x0;
+    while (__any(running)) {
+        rd.events(running, kSegEventNeed);
+        for (int half = 0; half < 2; half++) {
+            const bool have = running && rd.level() >= kSegHalfNeed;
+            const bool f4 = have && s.pos + kSegGroupBits <= x0;
+            const bool f2 = have && s.pos + kSegGroupBits / 2 <= x0;
+            const bool f1 = have && s.pos + kSegGroupBits / 4 <= x0;
+            const uint32_t pairs = __any(f4) ? kS2Pairs : (__any(f2) ? kS2Pairs / 2 : kS2Pairs / 4);
+            bool fast = pairs == kS2Pairs ? f4 : (pairs == kS2Pairs / 2 ? f2 : f1);
+            bool general = running && !fast && rd.level() >= 2;
+            if (__any(fast)) {
+                s2_ck_meter(ck, s, fast, 2 * pairs);
+                fast = fast && s.stop == 0;
+                if (fast) general = s2_ring_group(pairs, rd, rb, s) == 0;
+            }
+            if (__any(general))
+                s2_count_general<false>(lit, canon, len4, rd, s, ck, general, s.pos + kLitBits > x0, x0, limit);
+            running = running && s.stop == 0 && s.pos < x0;
+        }
+    }
+}
+
+// What the writing pass needs from the counting pass.
+struct S2Plan {
+    // per lane = per segment
+    uint32_t n_int;   // intervals of the lane's chain (0: none)
+    uint32_t hn;      // ... of which in front of x0 (the chain through the window)
+    uint32_t P;       // intervals of the lanes to the left
+    uint32_t obase;   // output bytes in front of the lane's chain
+    uint32_t bbase;   // bulk lines in front of it
+    uint32_t hc, hb;  // bytes / bulk lines of the chain through the window
+    // uniform
+    uint32_t total;   // output bytes of the stream
+    uint32_t ni;      // intervals of the stream
+    uint32_t tb;      // stream byte position of the Adler-32 trailer
+    uint32_t seg;     // bits per segment
+};
+
+// Counting pass of one stream.  False: the stream was left PENDING (or is out of range).
+__device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit, uint32_t* ring, uint2* ckpt, const uint64_t sid,
+                                          S2Plan& plan) {
+    const int lane = threadIdx.x & (kWave - 1);
+    if (sid >= a.n) return false;
+    const uint32_t len4 = a.canon_len4[lane & 31];
+
+    // ---- stream set-up (uniform) ----
+    const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
+    const uint64_t o0 = a.out_off[sid], o1 = a.out_off[sid + 1];
+    const uint8_t* in = a.in + i0;
+    const uint64_t ilen = i1 - i0, ocap = o1 - o0;
+    // segments below 2^16 bits (their chains may run on a little) and slots below 16 MiB: what a checkpoint can hold
+    bool ours = ilen < (1ull << 19) && ocap < (1ull << 24) && ilen * 8 >= a.canon_bits + 44ull;
+    const uint32_t in_bits = (uint32_t)(ilen * 8);
+    const uint32_t cap = (uint32_t)ocap;
+    if (ours) {  // canonical prefix: lane k compares stream dword k
+        bool mismatch = false;
+        if (lane < 14) {
+            uint32_t v = 0;
+            const uint8_t* p = in + 4 * lane;
+            for (int k = 0; k < 4; k++) v |= (uint32_t)p[k] << (8 * k);
+            if (lane == 13) v &= (1u << (a.canon_bits - 13 * 32)) - 1;
+            mismatch = v != a.canon_hdr[lane];
+        }
+        ours = !__any(mismatch);
+    }
+    if (!ours) {
+        if (lane == 0) seg_leave_pending(a, sid);
+        return false;
+    }
+    const uint32_t data_bits = in_bits - a.canon_bits;
+    const uint32_t window = (uint64_t)in_bits * 4 <= (uint64_t)cap * 17 ? (uint32_t)kSegWindowShort : (uint32_t)kSegWindow;
+    const uint32_t nseg = min((uint32_t)kWave, max(1u, (data_bits + kSegMinBits - 1) / kSegMinBits));
+    const uint32_t seg = (data_bits + nseg - 1) / nseg;
+    const uint32_t seg_bit0 = a.canon_bits + (uint32_t)lane * seg;
+    const bool in_range = (uint32_t)lane < nseg && seg_bit0 < in_bits;
+    const uint32_t limit = in_range ? in_bits - seg_bit0 : 0;
+
+    SegReader rd;
+    rd.ring = ring;
+    rd.lane_off = (uint32_t)lane;
+    rd.buf_lo = a.in;
+    rd.buf_hi = a.in + a.in_off[a.n];
+    rd.gp = in;
+    rd.in_wr = rd.in_rd = 0;
+    rd.lo = rd.hi = rd.boff = 0;
+    for (int k = 0; k < kSegChunk; k++) rd.pend_a.w[k] = rd.pend_b.w[k] = 0;
+    rd.has_a = rd.has_b = false;
+    const uint32_t rb = lds_offset(ring) + 4 * (uint32_t)lane;
+
+    S2Ck hck, tck;  // checkpoints of the chain through the window / of the rest
+    hck.col = tck.col = ckpt + lane;
+    hck.slot = 0;
+    hck.last = kS2HeadSlots - 1;
+    tck.slot = kS2HeadSlots;
+    tck.last = kS2Slots - 1;
+    hck.m = tck.m = 0;
+
+    // ---- guessed chain from bit 0 of the segment; count from where it leaves the window ----
+    S2Scan tail;
+    tail.pos = tail.cnt = tail.bl = tail.stop = tail.eob_bits = 0;
+    if (in_range) rd.start(in, seg_bit0);
+    s2_guess_scan(lit, a.canon_lit, rd, rb, limit, in_range, window, tail, tck);
+    uint32_t x0 = tail.stop == 0 ? tail.pos : 0;  // where the guessed chain left the window (0: it did not)
+    tail.cnt = 0;
+    {
+        const bool go = in_range && tail.stop == 0;
+        s2_ck_store(tck, tail, go);
+        s2_tail_scan(lit, a.canon_lit, rd, rb, limit, go, seg, tail, tck);
+    }
+
+    // ---- check: real start from the left neighbour, count through the window, must land on x0 ----
+    S2Scan head;
+    head.pos = head.cnt = head.bl = head.stop = head.eob_bits = 0;
+    uint32_t start = 0, cur_start = ~0u;
+    bool giveup = false;
+    for (int round = 0; round < 6; round++) {
+        const uint32_t prev_end = __shfl_up(tail.pos, 1, kWave);
+        const uint32_t prev_stop = __shfl_up(tail.stop, 1, kWave);
+        start = lane == 0 ? 0 : prev_end - seg;
+        const bool have_in = lane == 0 || (prev_stop == 0 && prev_end >= seg);
+        const bool need = in_range && have_in && start != cur_start;
+        if (!__any(need)) break;
+        if (round == 5) giveup = true;
+        if (need) {
+            head.pos = start;
+            head.cnt = head.bl = head.stop = head.eob_bits = 0;
+            hck.slot = 0;
+            hck.m = 0;
+            rd.start(in, seg_bit0 + start);
+        }
+        s2_ck_store(hck, head, need);
+        // a chain that did not leave the window has no x0: run the head to the window's end instead
+        s2_head_scan(lit, a.canon_lit, len4, rd, rb, limit, need, x0 ? x0 : window, head, hck);
+        const bool stopped_in_head = need && head.stop != 0;
+        const bool redo = need && head.stop == 0 && (head.pos != x0 || x0 == 0);
+        if (stopped_in_head) {  // end-of-block / fault inside the window: there is no tail
+            tail = head;
+            tail.cnt = tail.bl = 0;
+            x0 = head.pos;
+            tck.slot = kS2HeadSlots;
+            tck.m = 0;
+            s2_ck_store(tck, tail, true);  // (its end is stored below: an empty interval)
+        }
+        if (__any(redo)) {  // rare: re-count this segment from the landing point (the reader is there)
+            if (redo) {
+                tail.pos = head.pos;
+                tail.cnt = tail.bl = tail.stop = tail.eob_bits = 0;
+                x0 = head.pos;
+                tck.slot = kS2HeadSlots;
+                tck.m = 0;
+            }
+            s2_ck_store(tck, tail, redo);
+            s2_tail_scan(lit, a.canon_lit, rd, rb, limit, redo, seg, tail, tck);
+        }
+        if (need) cur_start = start;
+    }
+    // ---- the ends of both chains are checkpoints too ----
+    s2_ck_store(hck, head, in_range);
+    s2_ck_store(tck, tail, in_range);
+
+    // ---- who is live: lanes up to the first stop on a verified chain ----
+    const bool verified = in_range && cur_start == start;
+    const uint64_t stop_mask = __ballot(verified && tail.stop != 0);
+    const uint64_t unver_mask = __ballot(!verified);
+    const int stop_lane = stop_mask ? __ffsll((unsigned long long)stop_mask) - 1 : kWave;
+    const int first_unver = unver_mask ? __ffsll((unsigned long long)unver_mask) - 1 : kWave;
+    const bool live = lane <= stop_lane;
+    const uint32_t stop_kind = __shfl(tail.stop, stop_lane & (kWave - 1), kWave);
+    bool ok = !giveup && stop_lane < kWave && first_unver > stop_lane && stop_kind == 1;
+    ok = ok && !__any(live && (head.stop == 2 || hck.slot < 2 || tck.slot < kS2HeadSlots + 2));
+    const uint32_t count = live ? head.cnt + tail.cnt : 0;
+    const uint32_t blines = live ? head.bl + tail.bl : 0;
+    const uint32_t n_int = live ? (hck.slot - 1) + (tck.slot - kS2HeadSlots - 1) : 0;
+    unsigned long long incl = count;
+    uint32_t incl_b = blines, incl_n = n_int;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const unsigned long long y = __shfl_up(incl, o, kWave);
+        const uint32_t yb = __shfl_up(incl_b, o, kWave), yn = __shfl_up(incl_n, o, kWave);
+        if (lane >= o) {
+            incl += y;
+            incl_b += yb;
+            incl_n += yn;
+        }
+    }
+    const unsigned long long total64 = __shfl(incl, kWave - 1, kWave);
+    ok = ok && total64 <= cap;
+    ok = ok && __shfl(incl_b, kWave - 1, kWave) < (1u << (32 - kS2PosBits));
+    const uint32_t eob_end = __shfl(seg_bit0 + tail.pos + tail.eob_bits, stop_lane & (kWave - 1), kWave);
+    const uint32_t tb = (eob_end + 7) >> 3;
+    ok = ok && (uint64_t)tb * 8 + 32 <= in_bits;
+    S2DBG(4, (uint32_t)total64, __shfl(incl_n, kWave - 1, kWave), seg, tb, (uint32_t)stop_lane | ((uint32_t)first_unver << 8) | (stop_kind << 16) | ((giveup ? 1u : 0u) << 24), ok ? 1u : 0u, __shfl(incl_b, kWave - 1, kWave));
+    if (!ok) {
+        if (lane == 0) seg_leave_pending(a, sid);
+        return false;
+    }
+    plan.n_int = n_int;
+    plan.hn = live ? hck.slot - 1 : 0;
+    plan.P = incl_n - n_int;
+    plan.obase = (uint32_t)incl - count;
+    plan.bbase = incl_b - blines;
+    plan.hc = head.cnt;
+    plan.hb = head.bl;
+    plan.total = (uint32_t)total64;
+    plan.ni = __shfl(incl_n, kWave - 1, kWave);
+    plan.tb = tb;
+    plan.seg = seg;
+    return true;
+}
+
+// Flat reader of the writing pass: the lane's position in the input image.
+struct S2Flat {
+    const uint32_t* img;  // input image (LDS)
+    uint32_t wi;          // word index of the dword that follows hi
+    uint32_t lo, hi, boff;
+    __device__ __forceinline__ uint32_t raw_window() const { return __builtin_amdgcn_alignbit(hi, lo, boff); }
+    __device__ __forceinline__ uint32_t peek() const { return img[wi]; }
+    __device__ __forceinline__ void advance(uint32_t used, uint32_t nw) {
+        boff += used;
+        const bool wrap = boff >= 32;
+        boff &= 31;
+        lo = wrap ? hi : lo;
+        hi = wrap ? nw : hi;
+        wi += wrap ? 1u : 0u;
+    }
+};
+
+// Writing pass of one stream (plan from seg2_plan).
+__device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit, uint32_t* imgA, uint32_t* imgB, const uint2* ckpt,
+                                           const uint64_t sid, const S2Plan& plan) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t i0 = a.in_off[sid];
+    const uint8_t* in = a.in + i0;
+    const uint8_t* buf_lo = a.in;
+    const uint8_t* buf_hi = a.in + a.in_off[a.n];
+    uint8_t* op = a.out + a.out_off[sid];
+    const uint32_t pad0 = (uint32_t)(reinterpret_cast<uintptr_t>(op) & 15);
+    uint8_t* const line0 = op - pad0;  // 16-B aligned: virtual offset v <-> line0 + v
+    const uint32_t total = plan.total, ni = plan.ni, seg = plan.seg;
+    const uint32_t vend = pad0 + total;
+    const uint32_t ldsA = lds_offset(imgA), ldsB = lds_offset(imgB);
+    uint8_t* const imgB8 = reinterpret_cast<uint8_t*>(imgB);
+
+    // Image space: q = v - 16 x (bulk lines in front of v).  The output image holds q in
+    // [wq, wq + kS2OutCap); wq is a multiple of 16 and one piece below `qa`, up to which the image
+    // has been flushed (the piece in front supplies the byte a run at qa repeats).
+    uint32_t f0 = 0;             // next interval
+    uint32_t qa = 0;             // flushed up to here (multiple of 16)
+    uint32_t bla = 0;            // bulk lines in front of qa
+    // breaks: bulk lines taken out of the image at image position brk_q; entry i lives in lane i.
+    // Entries above the flushed part are carried from round to round.
+    uint32_t brk_q = 0, brk_k = 0, n_brk = 0;
+    uint32_t ad_a = 0;           // per-lane Adler-32 partials: sum of bytes,
+    long long ad_b = 0;          // sum of (total - offset) x byte
+    bool bad = false;
+    // zero the whole output image once; afterwards every round zeroes what it has used
+    for (uint32_t x = 16 * (uint32_t)lane; x < kS2OutCap; x += 16 * kWave)
+        *reinterpret_cast<uint4*>(imgB8 + x) = make_uint4(0, 0, 0, 0);
+
+    // The wavefront stores one run chain: `len` bytes from LDS address `addr` on, repeating the
+    // byte in front (all parameters uniform; bl_front = bulk lines in front of it).  A long chain
+    // leaves whole lines to global memory and a break in the image.
+    auto emit_chain = [&](uint32_t addr, uint32_t len, uint32_t bl_front, uint32_t wq) __attribute__((always_inline)) {
+        wave_sync();
+        const uint32_t xi = addr - ldsB;                   // image position
+        if (wq + xi == pad0) bad = true;                   // a run with nothing in front of it
+        const uint32_t byte = imgB8[xi - 1];
+        const uint32_t c4 = byte * 0x01010101u;
+        const uint32_t kl = len >= kS2LongRun ? len / 16 - 1 : 0u;
+        const uint32_t nimg = len - 16 * kl;               // bytes that pass through the image (< 64)
+        {   // image bytes [xi, xi + nimg): one dword per lane, byte-masked OR
+            const uint32_t dw = (xi & ~3u) + 4 * (uint32_t)lane;
+            const uint32_t lo_b = dw < xi ? xi - dw : 0u;                                            // first byte inside
+            const uint32_t hi_b = dw + 4 > xi + nimg ? (xi + nimg > dw ? xi + nimg - dw : 0u) : 4u;  // end
+            if (hi_b > lo_b) {
+                uint32_t m = hi_b >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi_b)) - 1);
+                m &= ~((1u << (8 * lo_b)) - 1);
+                __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(imgB8 + dw), c4 & m, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        wave_sync();
+        if (kl) {
+            const uint32_t h = (0u - xi) & 15u;              // image bytes in front of the lines
+            const uint32_t v = wq + xi + h + 16 * bl_front;  // virtual offset of the first line
+            const uint4 q = make_uint4(c4, c4, c4, c4);
+            S2DBG(2, xi, len, bl_front, v, kl, byte, wq);
+            for (uint32_t i = (uint32_t)lane; i < kl; i += kWave) *reinterpret_cast<uint4*>(line0 + v + 16 * (size_t)i) = q;
+            if (lane == 0) {  // 16 kl bytes of value `byte` at offsets off .. : sum (total - off - i) x byte
+                const long long m = 16ll * kl, off = (long long)v - pad0;
+                ad_a += (uint32_t)m * byte;
+                ad_b += (long long)byte * (m * ((long long)total - off) - m * (m - 1) / 2);
+            }
+            if (n_brk >= kS2MaxBreaks) {
+                bad = true;
+            } else {
+                if ((uint32_t)lane == n_brk) {
+                    brk_q = xi + h;
+                    brk_k = kl;
+                }
+                n_brk++;
+            }
+        }
+    };
+
+    while (f0 < ni) {
+        const uint32_t wq = qa - 16;  // (mod 2^32: the first round starts one piece in front of q = 0)
+        // ---- this lane's interval ----
+        const uint32_t f = f0 + (uint32_t)lane;
+        const bool valid = f < ni;
+        // owner segment: the last lane whose P <= f (binary search over the lanes' P by ds_bpermute; the
+        // lanes without intervals all lie behind the last live lane and have P = ni > f)
+        uint32_t sg = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const uint32_t probe = sg + step;
+            const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((probe & 63) << 2), (int)plan.P);
+            if (probe < (uint32_t)kWave && pv <= f) sg = probe;
+        }
+        const uint32_t sP = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.P);
+        const uint32_t sHn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.hn);
+        const uint32_t sOb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.obase);
+        const uint32_t sBb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.bbase);
+        const uint32_t sHc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.hc);
+        const uint32_t sHb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.hb);
+        const uint32_t k = f - sP;
+        const bool in_tail = k >= sHn;
+        const uint32_t slot = in_tail ? kS2HeadSlots + (k - sHn) : k;
+        uint2 c0 = make_uint2(0, 0), c1 = make_uint2(0, 0);
+        if (valid) {
+            c0 = ckpt[slot * kWave + sg];
+            c1 = ckpt[(slot + 1) * kWave + sg];
+        }
+        const uint32_t cbase = pad0 + sOb + (in_tail ? sHc : 0u);  // virtual offset of the chain part's first byte
+        const uint32_t bbase = sBb + (in_tail ? sHb : 0u);         // bulk lines in front of it
+        const uint32_t posmask = (1u << kS2PosBits) - 1;
+        const uint32_t seg_bit0 = a.canon_bits + sg * seg;
+        const uint32_t pos0 = seg_bit0 + (c0.x & posmask), pos1 = seg_bit0 + (c1.x & posmask);  // stream bits
+        const uint32_t bl0 = bbase + (c0.x >> kS2PosBits);                                       // bulk lines in front
+        const uint32_t q0 = cbase - 16 * bbase + c0.y, q1 = cbase - 16 * bbase + c1.y;          // image space
+
+        // ---- how many intervals fit the images ----
+        // input image: from the 16-B line of the first lane's first bit (2 bits in front of its token)
+        const uint8_t* g0 = in + ((pos0 - 2) >> 3);
+        const uint8_t* a0 = reinterpret_cast<const uint8_t*>(uni64(reinterpret_cast<uintptr_t>(g0)) & ~(uintptr_t)15);
+        const uint32_t ib = (uint32_t)(g0 - a0);  // this lane's first byte in the image
+        const bool fits = valid && ib + kS2InReach <= kS2InCap && (q1 - wq) + kS2OutReach <= kS2OutCap;
+        const uint64_t fit_mask = __ballot(fits);
+        const uint32_t n = fit_mask == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fit_mask);
+        if (n == 0) {  // cannot happen (one interval always fits); never loop for ever
+            bad = true;
+            break;
+        }
+        const bool act = (uint32_t)lane < n;
+
+        // ---- input image: kS2InCap bytes from a0, coalesced ----
+        {
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
+                const uint8_t* p = a0 + x;
+                v[i] = make_uint4(0, 0, 0, 0);
+                if (x < kS2InCap) {
+                    if (p >= buf_lo && p + 16 <= buf_hi) {
+                        v[i] = *reinterpret_cast<const uint4*>(p);
+                    } else {
+                        const SegChunk ch = seg_load_edge(p, buf_lo, buf_hi);
+                        v[i] = make_uint4(ch.w[0], ch.w[1], ch.w[2], ch.w[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
+                if (x < kS2InCap) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(imgA) + x) = v[i];
+            }
+        }
+        wave_sync();
+        // ---- lane set-up ----
+        S2Flat rd;
+        rd.img = imgA;
+        rd.wi = act ? (ib >> 2) + 2 : 2u;
+        rd.lo = imgA[rd.wi - 2];
+        rd.hi = imgA[rd.wi - 1];
+        rd.boff = 8 * (ib & 3) + ((pos0 - 2) & 7);
+        const uint32_t oaddr0 = ldsB + (q0 - wq);
+        uint32_t oaddr = oaddr0;  // LDS address of the lane's next output byte
+        uint32_t acc = 0;
+        uint32_t bl_here = bl0;   // bulk lines in front of the lane's position
+        // runs whose byte in front is not in the image yet (a run at the very start of an interval, or
+        // right behind such a run) wait for the end of the round: one per half
+        uint32_t def_len[4] = {0, 0, 0, 0}, def_addr[4] = {0, 0, 0, 0}, def_bl[4] = {0, 0, 0, 0};
+        uint32_t def_end = oaddr0;  // a chain that starts here must wait
+
+        // ---- four halves: a group of look-ups, then the run chains the lanes stopped at ----
+#pragma unroll
+        for (int half = 0; half < 4; half++) {
+            uint32_t e = 1;
+            if (act) {
+                uint32_t c = rd.boff | (oaddr << 6);
+                uint32_t ra = ldsA + 4 * rd.wi;
+                const uint32_t ra0 = ra;
+                e = seg2_write_group(kS2Pairs, rd.lo, rd.hi, c, ra, acc);
+                rd.wi += (ra - ra0) >> 2;
+                rd.boff = c & 63u;
+                oaddr = c >> 6;
+            }
+            // stream bit of the lane's next token
+            uint32_t pos = 8 * ((uint32_t)(a0 - in) + 4 * (rd.wi - 2)) + rd.boff + 2;
+            bool go = act && e == 0 && pos < pos1;
+            if (__any(go)) {
+                const bool mine = go;
+                uint32_t chain = 0;
+                for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
+                    const uint32_t raw = rd.raw_window();
+                    const uint32_t nw = rd.peek();
+                    const S2Tok t = s2_token(lit, a.canon_lit, 0u, raw, go, false);
+                    // only runs are decoded here; anything else inside the interval contradicts the counting pass
+                    const bool step = go && t.run != 0 && !t.bad;
+                    bad = bad || (go && rep == 0 && !step);
+                    chain += step ? t.run : 0u;
+                    const uint32_t adv = step ? t.used : 0u;
+                    pos += adv;
+                    rd.advance(adv, nw);
+                    go = step && pos < pos1;
+                }
+                const bool have = mine && chain != 0;
+                const bool wait = have && oaddr == def_end;
+                const uint32_t kl_mine = chain >= kS2LongRun ? chain / 16 - 1 : 0u;
+                // the chains of this half whose byte in front is there, lane by lane (uniform parameters)
+                uint64_t todo = __ballot(have && !wait);
+                while (todo) {
+                    const int src = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    const uint32_t u_addr = __shfl(oaddr, src, kWave), u_len = __shfl(chain, src, kWave);
+                    const uint32_t u_bl = __shfl(bl_here, src, kWave);
+                    emit_chain(uni(u_addr), uni(u_len), uni(u_bl), wq);
+                }
+                if (wait) {
+                    def_len[half] = chain;
+                    def_addr[half] = oaddr;
+                    def_bl[half] = bl_here;
+                    def_end = oaddr + chain - 16 * kl_mine;
+                }
+                if (have) {
+                    oaddr += chain - 16 * kl_mine;
+                    bl_here += kl_mine;
+                    acc = 0;
+                }
+            }
+        }
+        // every lane must have reached the end of its interval
+        {
+            const uint32_t pos = 8 * ((uint32_t)(a0 - in) + 4 * (rd.wi - 2)) + rd.boff + 2;
+            bad = bad || (act && pos < pos1);
+        }
+        // ---- the runs that waited, in output order (lane by lane, half by half) ----
+        {
+            uint64_t todo = __ballot(act && (def_len[0] | def_len[1] | def_len[2] | def_len[3]) != 0);
+            while (todo) {
+                const int src = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t u_len = uni(__shfl(def_len[h], src, kWave));
+                    const uint32_t u_addr = __shfl(def_addr[h], src, kWave), u_bl = __shfl(def_bl[h], src, kWave);
+                    if (u_len) emit_chain(uni(u_addr), u_len, uni(u_bl), wq);
+                }
+            }
+        }
+        S2DBG(3, f0, n, (uint32_t)__ballot(bad), (uint32_t)(__ballot(bad) >> 32), (uint32_t)__ballot(act && (8 * ((uint32_t)(a0 - in) + 4 * (rd.wi - 2)) + rd.boff + 2) < pos1), 0, 0);
+        if (__any(bad)) {
+            bad = true;
+            break;
+        }
+        wave_sync();
+        // ---- flush: whole 128-B lines of the image (everything once the stream ends) ----
+        const uint32_t qf_new = __shfl(q1, (int)(n - 1), kWave);  // image-space end of this round
+        const bool final_round = f0 + n >= ni;
+        const uint32_t qa_new = final_round ? (qf_new + 15) & ~15u : max(qa, qf_new & ~127u);
+        const uint32_t xa_new = qa_new - wq;
+        S2DBG(1, f0, n, wq, qa, qf_new, qa_new, n_brk | (bla << 8));
+        for (uint32_t x = 16 + 16 * (uint32_t)lane; x < xa_new; x += 16 * kWave) {
+            uint4 q = *reinterpret_cast<const uint4*>(imgB8 + x);
+            // bulk lines in front of this piece: those in front of qa + the breaks at or below it
+            uint32_t lines = bla;
+            for (uint32_t i = 0; i < n_brk; i++) {
+                // (readlane, not a shuffle: the lane that holds entry i may have left this loop already)
+                const uint32_t bq = __builtin_amdgcn_readlane(brk_q, (int)i), bk = __builtin_amdgcn_readlane(brk_k, (int)i);
+                lines += x >= bq ? bk : 0u;
+            }
+            const uint32_t v = wq + x + 16 * lines;
+            if (v >= pad0 && v + 16 <= vend) {
+                *reinterpret_cast<uint4*>(line0 + v) = q;
+            } else {  // first / last piece of the stream: only its own bytes, stored and summed
+                uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (uint32_t kk = 0; kk < 16; kk++) {
+                    const bool inside = v + kk >= pad0 && v + kk < vend;
+                    if (inside) line0[v + kk] = (uint8_t)(w[kk >> 2] >> (8 * (kk & 3)));
+                    if (!inside) w[kk >> 2] &= ~(0xFFu << (8 * (kk & 3)));
+                }
+                q = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // Adler-32: sum of bytes, sum of (total - offset) x byte
+            const uint32_t sum = bytesum4(q.x) + bytesum4(q.y) + bytesum4(q.z) + bytesum4(q.w);
+            uint32_t u = bytedot4(q.x, 0x03020100u, 0);
+            u = bytedot4(q.y, 0x07060504u, u);
+            u = bytedot4(q.z, 0x0b0a0908u, u);
+            u = bytedot4(q.w, 0x0f0e0d0cu, u);
+            ad_a += sum;
+            ad_b += ((long long)total - ((long long)v - pad0)) * (long long)sum - (long long)u;
+        }
+        if (!final_round) {
+            // ---- breaks: the flushed ones join bla, the others move with the image ----
+            if (n_brk) {
+                const bool mine = (uint32_t)lane < n_brk;
+                const bool done = mine && brk_q < xa_new;
+                bla += wave_sum_u32(done ? brk_k : 0u);
+                const uint64_t keep_mask = __ballot(mine && !done);
+                const uint32_t rank = (uint32_t)__popcll(keep_mask & lanemask_lt(lane));
+                const uint32_t nq = brk_q - (xa_new - 16), nk = brk_k;
+                // push entry -> lane `rank` (lanes that push nothing aim at lane 63 + their own data is ignored below)
+                const uint32_t dst = (mine && !done) ? rank : 63u;
+                const uint32_t gq = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)((mine && !done) ? nq : 0u));
+                const uint32_t gk = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)((mine && !done) ? nk : 0u));
+                n_brk = (uint32_t)__popcll(keep_mask);
+                brk_q = (uint32_t)lane < n_brk ? gq : 0u;
+                brk_k = (uint32_t)lane < n_brk ? gk : 0u;
+                if (n_brk == kS2MaxBreaks) bad = true;  // (lane 63 would be ambiguous)
+            }
+            // ---- carry: the pieces from one below qa_new on move to the front of the image, the rest is zeroed ----
+            const uint32_t src0 = xa_new - 16;                        // first piece that stays
+            const uint32_t keep_end = ((qf_new + 15) & ~15u) - wq;    // pieces below this hold bytes of the stream
+            const uint32_t used_end = min(kS2OutCap, (keep_end + kS2OutReach + 15) & ~15u);
+            const uint32_t sx = src0 + 16 * (uint32_t)lane;
+            uint4 keep = make_uint4(0, 0, 0, 0);
+            if (sx < keep_end) keep = *reinterpret_cast<const uint4*>(imgB8 + sx);
+            wave_sync();  // every lane has read before any lane writes
+            *reinterpret_cast<uint4*>(imgB8 + 16 * (uint32_t)lane) = keep;
+            for (uint32_t x = 16 * (uint32_t)(lane + kWave); x < used_end; x += 16 * kWave)
+                *reinterpret_cast<uint4*>(imgB8 + x) = make_uint4(0, 0, 0, 0);
+            wave_sync();
+        }
+        qa = qa_new;
+        f0 += n;
+    }
+    if (__any(bad)) {
+        if (lane == 0) seg_leave_pending(a, sid);
+        return;
+    }
+    // ---- Adler-32: A = 1 + sum of bytes ; B = total + sum of (total - offset) x byte ----
+    uint32_t pa = ad_a % kAdlerMod;
+    uint32_t pb = (uint32_t)(((ad_b % (long long)kAdlerMod) + kAdlerMod) % kAdlerMod);
+    pa = wave_sum_u32(pa);
+    pb = wave_sum_u32(pb);
+    const uint32_t A = (1u + pa) % kAdlerMod;
+    const uint32_t B = (uint32_t)(((uint64_t)total + pb) % kAdlerMod);
+    const uint32_t adler = (B << 16) | A;
+    S2DBG(5, adler, total, 0, 0, 0, 0, 0);
+    if (lane == 0) {
+        const uint32_t tb = plan.tb;
+        // src/decompress.rs:306-326: byte boundary, then the big-endian Adler-32
+        const uint32_t stored = ((uint32_t)in[tb] << 24) | ((uint32_t)in[tb + 1] << 16) | ((uint32_t)in[tb + 2] << 8) |
+                                (uint32_t)in[tb + 3];
+        if (stored == adler || (a.flags & 1u)) {
+            a.status[sid] = ST_OK;
+            a.out_len[sid] = total;
+            if (a.adler) a.adler[sid] = adler;
+        } else {
+            seg_leave_pending(a, sid);  // the exact kernels report WrongChecksum
+        }
+    }
+}
+
+__device__ __forceinline__ void seg2_decode(const SegArgs& a, Seg2Lds& L, uint2* ckpt, const uint64_t sid) {
+    const uint32_t wid = threadIdx.x / kWave;
+    uint32_t* A = L.a + wid * kS2AWords;
+    uint32_t* B = L.b + wid * kS2BWords;
+    S2Plan plan;
+    if (seg2_plan(a, L.lit, A, ckpt, sid, plan)) seg2_write(a, L.lit, A, B, ckpt, sid, plan);
+}
+
+}  // namespace fdh

@@ -142,6 +142,8 @@ struct SegArgs {
     uint32_t pending;
     uint32_t* list;  // nullable: [0] = count, [4..] = ids of the streams left PENDING (compacted);
                      // [1] = next stream to hand out (persistent wavefronts fetch their work here)
+    const uint32_t* src_list;  // nullable: work on these streams only ([0] = count, [4..] = ids)
+    uint2* ckpt;     // interval decoder (inflate_seg2.h): checkpoint scratch, kS2CkptPerWave entries per wavefront
 };
 
 // Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).
