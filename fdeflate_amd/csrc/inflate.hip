@@ -41,6 +41,12 @@ struct CanonTables {
     uint32_t eof[4];
     uint32_t hdr[16];  // the prefix as little-endian dwords (14 used)
     uint32_t len4[32]; // code lengths of the literals 0..255, 4 bits each (segment kernel: first literal of a step)
+    // interval kernel: the symbols that are no literals (256 .. 285), decoded without a table in memory.
+    // nl[0..16): per code length l: first such code (canonical, MSB first) | their number << 16 | index of
+    // the first one in nl[32..] << 22.  nl[16] = shortest, nl[17] = longest such length.
+    // nl[32..64): the symbols in (length, symbol) order: length base | extra bits << 9 | 1 << 12 for a
+    // length symbol, 1 << 13 for end-of-block (256, and 286 / 287: reference src/tables.rs:100)
+    uint32_t nl[64];
     uint32_t status;   // build status (ST_OK expected)
 };
 __device__ CanonTables g_canon;
@@ -372,6 +378,36 @@ __global__ __launch_bounds__(kWave) void canon_build_kernel() {
         g_canon.len4[lane] = w;
     }
     if (lane == 0) {
+        // canonical bookkeeping of the symbols >= 256 (uniform, once per device)
+        uint32_t code = 0, prev = 0, off = 0, lmin = 0, lmax = 0;
+        for (uint32_t l = 0; l < 64; l++) g_canon.nl[l] = 0;
+        for (uint32_t l = 1; l <= 15; l++) {
+            uint32_t all = 0, lits = 0;
+            for (uint32_t sy = 0; sy < 288; sy++) {
+                if (lds.hs.lens[sy] == l) {
+                    all++;
+                    if (sy < 256) lits++;
+                }
+            }
+            code = (code + prev) << 1;
+            prev = all;
+            const uint32_t nn = all - lits;
+            if (l <= 15) g_canon.nl[l] = (code + lits) | (nn << 16) | (off << 22);
+            if (nn) {
+                if (!lmin) lmin = l;
+                lmax = l;
+                for (uint32_t sy = 256; sy < 288; sy++) {
+                    if (lds.hs.lens[sy] == l && off < 32) {
+                        g_canon.nl[32 + off] = (sy == 256 || sy >= 286)
+                                                   ? (1u << 13)
+                                                   : ((uint32_t)kLenBase[sy - 257] | ((uint32_t)kLenExtra[sy - 257] << 9) | (1u << 12));
+                        off++;
+                    }
+                }
+            }
+        }
+        g_canon.nl[16] = lmin;
+        g_canon.nl[17] = lmax;
         g_canon.eof[0] = inf.eof_code;
         g_canon.eof[1] = inf.eof_mask;
         g_canon.eof[2] = inf.eof_bits;
@@ -460,6 +496,14 @@ extern "C" int fdh_debug_s2(uint32_t* host, uint32_t sid) {  // returns the reco
     hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_s2dbg_n), &z, 4);
     hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_s2dbg_sid), &sid, 4);
     return (int)nrec;
+}
+#endif
+
+#ifdef FDH_S2_DEBUG
+extern "C" int fdh_debug_s2time(uint32_t* host) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_s2time), 4096 * 16 * 4);
+    return 0;
 }
 #endif
 
@@ -552,7 +596,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             if (e != hipSuccess) return (int)e;
         }
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->len4, canon->hdr,
-                        fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr};
+                        fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr, canon->nl};
         if (list && seg2) {  // interval kernel first; what it leaves goes through the segment kernel
             sa.ckpt = reinterpret_cast<uint2*>(list + list_words);
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);

@@ -74,8 +74,17 @@ __device__ uint32_t g_s2dbg_sid = 0xFFFFFFFFu;
             }                                                                                      \
         }                                                                                          \
     } while (0)
+__device__ uint32_t g_s2time[4096 * 16];
+#define S2T(k) do { if (sid < 4096 && lane == 0) g_s2time[sid * 16 + (k)] = (uint32_t)clock64(); } while (0)
+#define S2ACC_DECL uint32_t s2acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long s2t_ = clock64()
+#define S2ACC(k) do { const long long n_ = clock64(); s2acc_[k] += (uint32_t)(n_ - s2t_); s2t_ = n_; } while (0)
+#define S2ACC_OUT do { if (sid < 4096 && lane == 0) for (int k_ = 0; k_ < 8; k_++) g_s2time[sid * 16 + 8 + k_] = s2acc_[k_]; } while (0)
 #else
 #define S2DBG(tag, a0, a1, a2, a3, a4, a5, a6) do { } while (0)
+#define S2T(k) do { } while (0)
+#define S2ACC_DECL do { } while (0)
+#define S2ACC(k) do { } while (0)
+#define S2ACC_OUT do { } while (0)
 #endif
 
 struct Seg2Lds {
@@ -85,19 +94,36 @@ struct Seg2Lds {
 };
 static_assert(sizeof(Seg2Lds) == 160 * 1024, "one workgroup owns the LDS of its CU");
 
+// The symbols that are no literals, decoded without a table in memory (CanonTables::nl): two
+// "lane tables", lane l of `parm` = the bookkeeping of code length l, lane k of `tab` = the k-th such
+// symbol, and the range of lengths to try (uniform).
+struct S2Codes {
+    uint32_t parm, tab, lmin, lmax, len4;
+};
+__device__ __forceinline__ S2Codes s2_codes(const SegArgs& a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    S2Codes c;
+    c.parm = a.canon_nl[lane & 31];
+    c.tab = a.canon_nl[32 + (lane & 31)];
+    c.lmin = uni(a.canon_nl[16]);
+    c.lmax = uni(a.canon_nl[17]);
+    c.len4 = a.canon_len4[lane & 31];
+    return c;
+}
+
 // One token in its general, select-only form (the step behind a group).  `raw` = 32 window bits,
-// the token starting at bit 2.  A literal step is read from the LDS table; for a zero entry the lanes
-// that `need` the token fetch it from the canonical table in global memory (device layout of
-// inflate_tables.h).  `single`: take the first literal of a literal step alone (its length comes from
-// `len4`, 256 x 4 bits in one VGPR, read with ds_bpermute).  Call with all lanes active.
+// the token starting at bit 2.  A literal step is read from the LDS table; a zero entry there means
+// a run length / end-of-block / impossible code, which the lanes that `need` the token decode by
+// walking the canonical code lengths (a prefix code matches at exactly one length).  `single`: take
+// the first literal of a literal step alone (its length comes from len4, 256 x 4 bits in one VGPR,
+// read with ds_bpermute).  Call with all lanes active.
 struct S2Tok {
     uint32_t used;  // stream bits
     uint32_t nlit;  // literals (0 for a run / end-of-block / impossible token)
     uint32_t run;   // run length (0: not a run)
     bool eob, bad;
 };
-__device__ __forceinline__ S2Tok s2_token(const uint32_t* lit, const uint32_t* canon, uint32_t len4, uint32_t raw, bool need,
-                                          bool single) {
+__device__ __forceinline__ S2Tok s2_token(const uint32_t* lit, const S2Codes& cd, uint32_t raw, bool need, bool single) {
     const uint32_t w = raw >> 2;
     const uint32_t idx = w & (kLitSize - 1);
     const uint32_t e = lit[idx];
@@ -109,18 +135,26 @@ __device__ __forceinline__ S2Tok s2_token(const uint32_t* lit, const uint32_t* c
     const bool first_only = single && t.nlit > 1;
     if (__any(need && first_only)) {
         const uint32_t b1 = (e >> 8) & 0xFF;
-        const uint32_t ww = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b1 >> 3) << 2), (int)len4);
+        const uint32_t ww = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b1 >> 3) << 2), (int)cd.len4);
         const uint32_t len1 = (ww >> ((b1 & 7) * 4)) & 15;
         t.used = first_only ? len1 : t.used;
         t.nlit = first_only ? 1u : t.nlit;
     }
     const bool other = need && e == 0;
     if (__any(other)) {
-        uint32_t cl = K_LONG << 4;
-        if (other) cl = canon[idx];
-        const uint32_t kind = (cl >> 4) & 15, nb = cl & 15, ex = (cl >> 8) & 31, base = cl >> 16;
-        const bool is_run = other && kind == K_LEN;
-        const bool is_eob = other && kind == K_EOB;
+        const uint32_t r = __brev(w) >> 2;  // the 30 stream bits, first bit on top
+        uint32_t k = 0, nb = 0;
+        for (uint32_t l = cd.lmin; l <= cd.lmax; l++) {
+            const uint32_t p = __builtin_amdgcn_readlane(cd.parm, (int)l);
+            const uint32_t d = (r >> (30 - l)) - (p & 0xFFFFu);
+            const bool hit = d < ((p >> 16) & 63u);
+            k = hit ? (p >> 22) + d : k;
+            nb = hit ? l : nb;
+        }
+        const uint32_t ent = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((k & 31) << 2), (int)cd.tab);
+        const bool is_run = other && nb != 0 && (ent & (1u << 12)) != 0;
+        const bool is_eob = other && nb != 0 && (ent & (1u << 13)) != 0;
+        const uint32_t ex = (ent >> 9) & 7, base = ent & 511u;
         t.run = is_run ? base + ((w >> nb) & ((1u << ex) - 1)) : 0u;
         t.used = is_run ? nb + ex + 1 : (is_eob ? nb : t.used);
         t.eob = is_eob;
@@ -182,7 +216,7 @@ __device__ __forceinline__ uint32_t s2_ring_group(uint32_t pairs, SegReader& rd,
 // pos < end).  GUESS: nothing is counted, an impossible token or a stray end-of-block slides on by
 // one bit.  Otherwise the bytes are counted, the meter runs and a halt is recorded in s.stop.
 template <bool GUESS>
-__device__ __forceinline__ void s2_count_general(const uint32_t* lit, const uint32_t* canon, uint32_t len4, SegReader& rd,
+__device__ __forceinline__ void s2_count_general(const uint32_t* lit, const S2Codes& cd, SegReader& rd,
                                                  S2Scan& s, S2Ck& ck, bool take, bool single, uint32_t end, uint32_t limit) {
     bool go = take;
     uint32_t chain = 0;
@@ -190,7 +224,7 @@ __device__ __forceinline__ void s2_count_general(const uint32_t* lit, const uint
         if (rep && __any(go && rd.level() < 2)) rd.refill_now();  // chains must not depend on what the ring happens to hold
         const uint32_t raw = rd.raw_window();
         const uint32_t nw = rd.peek();
-        S2Tok t = s2_token(lit, canon, len4, raw, go, single && rep == 0);
+        S2Tok t = s2_token(lit, cd, raw, go, single && rep == 0);
         const bool accept = go && (rep == 0 || t.run != 0);
         if (GUESS) {
             const bool slide = accept && (t.bad || t.eob) && s.pos + 1 <= limit;
@@ -222,7 +256,7 @@ __device__ __forceinline__ void s2_count_general(const uint32_t* lit, const uint
 }
 
 // Guessed chain through the window: from s.pos until pos >= window.  Nothing is counted.
-__device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const uint32_t* canon, SegReader& rd, uint32_t rb,
+__device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const S2Codes& cd, SegReader& rd, uint32_t rb,
                                               uint32_t limit, bool active, uint32_t window, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < window;
     while (__any(running)) {
@@ -233,7 +267,7 @@ __device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const uint32_
             if (__any(fast)) {
                 if (fast) general = s2_ring_group(kS2Pairs, rd, rb, s) == 0;
             }
-            if (__any(general)) s2_count_general<true>(lit, canon, 0u, rd, s, ck, general, false, window, limit);
+            if (__any(general)) s2_count_general<true>(lit, cd, rd, s, ck, general, false, window, limit);
             running = running && s.stop == 0 && s.pos < window;
         }
     }
@@ -241,30 +275,33 @@ __device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const uint32_
 
 // The long loop of the counting pass: from s.pos until pos >= stop_at (the lane's range ends
 // somewhere inside a group: any symbol boundary will do for the neighbour), every byte counted.
-__device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const uint32_t* canon, SegReader& rd, uint32_t rb,
+__device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes& cd, SegReader& rd, uint32_t rb,
                                              uint32_t limit, bool active, uint32_t stop_at, S2Scan& s, S2Ck& ck) {
     bool running = active && s.stop == 0 && s.pos < stop_at;
     if (running) rd.refill_now();
     while (__any(running)) {
         rd.events(running, kSegEventNeed);
-        for (int half = 0; half < 2; half++) {
-            bool fast = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
-            bool general = running && !fast && rd.level() >= 2;
-            if (__any(fast)) {
-                s2_ck_meter(ck, s, fast, 2 * kS2Pairs);
-                fast = fast && s.stop == 0;
-                if (fast) general = s2_ring_group(kS2Pairs, rd, rb, s) == 0;
-            }
-            if (__any(general)) s2_count_general<false>(lit, canon, 0u, rd, s, ck, general, false, stop_at, limit);
-            running = running && s.stop == 0 && s.pos < stop_at;
+        // one group per event: 16 look-ups for the lanes that have the input for it (what an event
+        // guarantees), or, when no lane has, 8; a lane that cannot take part takes one token
+        const bool f2 = running && s.pos + 2 * kSegGroupBits <= limit && rd.level() >= kSegEventNeed;
+        const bool f1 = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
+        const uint32_t pairs = __any(f2) ? 2 * kS2Pairs : kS2Pairs;
+        bool fast = pairs == kS2Pairs ? f1 : f2;
+        bool general = running && !fast && rd.level() >= 2;
+        if (__any(fast)) {
+            s2_ck_meter(ck, s, fast, 2 * pairs);
+            fast = fast && s.stop == 0;
+            if (fast) general = s2_ring_group(pairs, rd, rb, s) == 0;
         }
+        if (__any(general)) s2_count_general<false>(lit, cd, rd, s, ck, general, false, stop_at, limit);
+        running = running && s.stop == 0 && s.pos < stop_at;
     }
 }
 
 // The real chain through the window: from s.pos to x0, where it must land exactly.  Groups while
 // they cannot pass x0, then token by token, and one literal at a time once a whole step could pass
 // x0 (the guessed and the real chain may group literals differently).
-__device__ __forceinline__ void s2_head_scan(const uint32_t* lit, const uint32_t* canon, uint32_t len4, SegReader& rd,
+__device__ __forceinline__ void s2_head_scan(const uint32_t* lit, const S2Codes& cd, SegReader& rd,
                                              uint32_t rb, uint32_t limit, bool active, uint32_t x0, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < x0;
     while (__any(running)) {
@@ -283,7 +320,7 @@ __device__ __forceinline__ void s2_head_scan(const uint32_t* lit, const uint32_t
                 if (fast) general = s2_ring_group(pairs, rd, rb, s) == 0;
             }
             if (__any(general))
-                s2_count_general<false>(lit, canon, len4, rd, s, ck, general, s.pos + kLitBits > x0, x0, limit);
+                s2_count_general<false>(lit, cd, rd, s, ck, general, s.pos + kLitBits > x0, x0, limit);
             running = running && s.stop == 0 && s.pos < x0;
         }
     }
@@ -310,7 +347,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
                                           S2Plan& plan) {
     const int lane = threadIdx.x & (kWave - 1);
     if (sid >= a.n) return false;
-    const uint32_t len4 = a.canon_len4[lane & 31];
+    const S2Codes cd = s2_codes(a);
 
     // ---- stream set-up (uniform) ----
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
@@ -367,16 +404,19 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     // ---- guessed chain from bit 0 of the segment; count from where it leaves the window ----
     S2Scan tail;
     tail.pos = tail.cnt = tail.bl = tail.stop = tail.eob_bits = 0;
+    S2T(0);
     if (in_range) rd.start(in, seg_bit0);
-    s2_guess_scan(lit, a.canon_lit, rd, rb, limit, in_range, window, tail, tck);
+    s2_guess_scan(lit, cd, rd, rb, limit, in_range, window, tail, tck);
     uint32_t x0 = tail.stop == 0 ? tail.pos : 0;  // where the guessed chain left the window (0: it did not)
     tail.cnt = 0;
+    S2T(1);
     {
         const bool go = in_range && tail.stop == 0;
         s2_ck_store(tck, tail, go);
-        s2_tail_scan(lit, a.canon_lit, rd, rb, limit, go, seg, tail, tck);
+        s2_tail_scan(lit, cd, rd, rb, limit, go, seg, tail, tck);
     }
 
+    S2T(2);
     // ---- check: real start from the left neighbour, count through the window, must land on x0 ----
     S2Scan head;
     head.pos = head.cnt = head.bl = head.stop = head.eob_bits = 0;
@@ -399,7 +439,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
         }
         s2_ck_store(hck, head, need);
         // a chain that did not leave the window has no x0: run the head to the window's end instead
-        s2_head_scan(lit, a.canon_lit, len4, rd, rb, limit, need, x0 ? x0 : window, head, hck);
+        s2_head_scan(lit, cd, rd, rb, limit, need, x0 ? x0 : window, head, hck);
         const bool stopped_in_head = need && head.stop != 0;
         const bool redo = need && head.stop == 0 && (head.pos != x0 || x0 == 0);
         if (stopped_in_head) {  // end-of-block / fault inside the window: there is no tail
@@ -419,10 +459,11 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
                 tck.m = 0;
             }
             s2_ck_store(tck, tail, redo);
-            s2_tail_scan(lit, a.canon_lit, rd, rb, limit, redo, seg, tail, tck);
+            s2_tail_scan(lit, cd, rd, rb, limit, redo, seg, tail, tck);
         }
         if (need) cur_start = start;
     }
+    S2T(3);
     // ---- the ends of both chains are checkpoints too ----
     s2_ck_store(hck, head, in_range);
     s2_ck_store(tck, tail, in_range);
@@ -434,7 +475,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     const int stop_lane = stop_mask ? __ffsll((unsigned long long)stop_mask) - 1 : kWave;
     const int first_unver = unver_mask ? __ffsll((unsigned long long)unver_mask) - 1 : kWave;
     const bool live = lane <= stop_lane;
-    const uint32_t stop_kind = __shfl(tail.stop, stop_lane & (kWave - 1), kWave);
+    const uint32_t stop_kind = __builtin_amdgcn_readlane(tail.stop, stop_lane & (kWave - 1));
     bool ok = !giveup && stop_lane < kWave && first_unver > stop_lane && stop_kind == 1;
     ok = ok && !__any(live && (head.stop == 2 || hck.slot < 2 || tck.slot < kS2HeadSlots + 2));
     const uint32_t count = live ? head.cnt + tail.cnt : 0;
@@ -452,10 +493,11 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
             incl_n += yn;
         }
     }
-    const unsigned long long total64 = __shfl(incl, kWave - 1, kWave);
+    const unsigned long long total64 = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(incl >> 32), kWave - 1) << 32) |
+                                       __builtin_amdgcn_readlane((uint32_t)incl, kWave - 1);
     ok = ok && total64 <= cap;
-    ok = ok && __shfl(incl_b, kWave - 1, kWave) < (1u << (32 - kS2PosBits));
-    const uint32_t eob_end = __shfl(seg_bit0 + tail.pos + tail.eob_bits, stop_lane & (kWave - 1), kWave);
+    ok = ok && __builtin_amdgcn_readlane(incl_b, kWave - 1) < (1u << (32 - kS2PosBits));
+    const uint32_t eob_end = __builtin_amdgcn_readlane(seg_bit0 + tail.pos + tail.eob_bits, stop_lane & (kWave - 1));
     const uint32_t tb = (eob_end + 7) >> 3;
     ok = ok && (uint64_t)tb * 8 + 32 <= in_bits;
     S2DBG(4, (uint32_t)total64, __shfl(incl_n, kWave - 1, kWave), seg, tb, (uint32_t)stop_lane | ((uint32_t)first_unver << 8) | (stop_kind << 16) | ((giveup ? 1u : 0u) << 24), ok ? 1u : 0u, __shfl(incl_b, kWave - 1, kWave));
@@ -471,9 +513,10 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     plan.hc = head.cnt;
     plan.hb = head.bl;
     plan.total = (uint32_t)total64;
-    plan.ni = __shfl(incl_n, kWave - 1, kWave);
+    plan.ni = __builtin_amdgcn_readlane(incl_n, kWave - 1);
     plan.tb = tb;
     plan.seg = seg;
+    S2T(4);
     return true;
 }
 
@@ -505,10 +548,11 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
     uint8_t* op = a.out + a.out_off[sid];
     const uint32_t pad0 = (uint32_t)(reinterpret_cast<uintptr_t>(op) & 15);
     uint8_t* const line0 = op - pad0;  // 16-B aligned: virtual offset v <-> line0 + v
-    const uint32_t total = plan.total, ni = plan.ni, seg = plan.seg;
+    const uint32_t total = uni(plan.total), ni = uni(plan.ni), seg = uni(plan.seg);
     const uint32_t vend = pad0 + total;
     const uint32_t ldsA = lds_offset(imgA), ldsB = lds_offset(imgB);
     uint8_t* const imgB8 = reinterpret_cast<uint8_t*>(imgB);
+    const S2Codes cd = s2_codes(a);
 
     // Image space: q = v - 16 x (bulk lines in front of v).  The output image holds q in
     // [wq, wq + kS2OutCap); wq is a multiple of 16 and one piece below `qa`, up to which the image
@@ -572,7 +616,9 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         }
     };
 
+    S2ACC_DECL;
     while (f0 < ni) {
+        S2ACC(0);
         const uint32_t wq = qa - 16;  // (mod 2^32: the first round starts one piece in front of q = 0)
         // ---- this lane's interval ----
         const uint32_t f = f0 + (uint32_t)lane;
@@ -621,6 +667,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
             break;
         }
         const bool act = (uint32_t)lane < n;
+        S2ACC(1);
 
         // ---- input image: kS2InCap bytes from a0, coalesced ----
         {
@@ -661,6 +708,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         // right behind such a run) wait for the end of the round: one per half
         uint32_t def_len[4] = {0, 0, 0, 0}, def_addr[4] = {0, 0, 0, 0}, def_bl[4] = {0, 0, 0, 0};
         uint32_t def_end = oaddr0;  // a chain that starts here must wait
+        S2ACC(2);
 
         // ---- four halves: a group of look-ups, then the run chains the lanes stopped at ----
 #pragma unroll
@@ -675,6 +723,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
                 rd.boff = c & 63u;
                 oaddr = c >> 6;
             }
+            S2ACC(3);
             // stream bit of the lane's next token
             uint32_t pos = 8 * ((uint32_t)(a0 - in) + 4 * (rd.wi - 2)) + rd.boff + 2;
             bool go = act && e == 0 && pos < pos1;
@@ -684,7 +733,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
                 for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
                     const uint32_t raw = rd.raw_window();
                     const uint32_t nw = rd.peek();
-                    const S2Tok t = s2_token(lit, a.canon_lit, 0u, raw, go, false);
+                    const S2Tok t = s2_token(lit, cd, raw, go, false);
                     // only runs are decoded here; anything else inside the interval contradicts the counting pass
                     const bool step = go && t.run != 0 && !t.bad;
                     bad = bad || (go && rep == 0 && !step);
@@ -702,9 +751,9 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
                 while (todo) {
                     const int src = __ffsll((unsigned long long)todo) - 1;
                     todo &= todo - 1;
-                    const uint32_t u_addr = __shfl(oaddr, src, kWave), u_len = __shfl(chain, src, kWave);
-                    const uint32_t u_bl = __shfl(bl_here, src, kWave);
-                    emit_chain(uni(u_addr), uni(u_len), uni(u_bl), wq);
+                    const uint32_t u_addr = __builtin_amdgcn_readlane(oaddr, src), u_len = __builtin_amdgcn_readlane(chain, src);
+                    const uint32_t u_bl = __builtin_amdgcn_readlane(bl_here, src);
+                    emit_chain(u_addr, u_len, u_bl, wq);
                 }
                 if (wait) {
                     def_len[half] = chain;
@@ -718,6 +767,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
                     acc = 0;
                 }
             }
+            S2ACC(4);
         }
         // every lane must have reached the end of its interval
         {
@@ -732,9 +782,9 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
                 todo &= todo - 1;
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
-                    const uint32_t u_len = uni(__shfl(def_len[h], src, kWave));
-                    const uint32_t u_addr = __shfl(def_addr[h], src, kWave), u_bl = __shfl(def_bl[h], src, kWave);
-                    if (u_len) emit_chain(uni(u_addr), u_len, uni(u_bl), wq);
+                    const uint32_t u_len = __builtin_amdgcn_readlane(def_len[h], src);
+                    const uint32_t u_addr = __builtin_amdgcn_readlane(def_addr[h], src), u_bl = __builtin_amdgcn_readlane(def_bl[h], src);
+                    if (u_len) emit_chain(u_addr, u_len, u_bl, wq);
                 }
             }
         }
@@ -744,8 +794,9 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
             break;
         }
         wave_sync();
+        S2ACC(5);
         // ---- flush: whole 128-B lines of the image (everything once the stream ends) ----
-        const uint32_t qf_new = __shfl(q1, (int)(n - 1), kWave);  // image-space end of this round
+        const uint32_t qf_new = __builtin_amdgcn_readlane(q1, (int)(n - 1));  // image-space end of this round
         const bool final_round = f0 + n >= ni;
         const uint32_t qa_new = final_round ? (qf_new + 15) & ~15u : max(qa, qf_new & ~127u);
         const uint32_t xa_new = qa_new - wq;
@@ -781,12 +832,13 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
             ad_a += sum;
             ad_b += ((long long)total - ((long long)v - pad0)) * (long long)sum - (long long)u;
         }
+        S2ACC(6);
         if (!final_round) {
             // ---- breaks: the flushed ones join bla, the others move with the image ----
             if (n_brk) {
                 const bool mine = (uint32_t)lane < n_brk;
                 const bool done = mine && brk_q < xa_new;
-                bla += wave_sum_u32(done ? brk_k : 0u);
+                bla += uni(wave_sum_u32(done ? brk_k : 0u));
                 const uint64_t keep_mask = __ballot(mine && !done);
                 const uint32_t rank = (uint32_t)__popcll(keep_mask & lanemask_lt(lane));
                 const uint32_t nq = brk_q - (xa_new - 16), nk = brk_k;
@@ -814,7 +866,10 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         }
         qa = qa_new;
         f0 += n;
+        S2ACC(7);
     }
+    S2ACC_OUT;
+    S2T(5);
     if (__any(bad)) {
         if (lane == 0) seg_leave_pending(a, sid);
         return;
@@ -848,7 +903,11 @@ __device__ __forceinline__ void seg2_decode(const SegArgs& a, Seg2Lds& L, uint2*
     uint32_t* A = L.a + wid * kS2AWords;
     uint32_t* B = L.b + wid * kS2BWords;
     S2Plan plan;
+#ifdef FDH_S2_SKIP_WRITE
+    if (seg2_plan(a, L.lit, A, ckpt, sid, plan) && (threadIdx.x & 63) == 0) seg_leave_pending(a, sid);
+#else
     if (seg2_plan(a, L.lit, A, ckpt, sid, plan)) seg2_write(a, L.lit, A, B, ckpt, sid, plan);
+#endif
 }
 
 }  // namespace fdh

@@ -144,6 +144,7 @@ struct SegArgs {
                      // [1] = next stream to hand out (persistent wavefronts fetch their work here)
     const uint32_t* src_list;  // nullable: work on these streams only ([0] = count, [4..] = ids)
     uint2* ckpt;     // interval decoder (inflate_seg2.h): checkpoint scratch, kS2CkptPerWave entries per wavefront
+    const uint32_t* canon_nl;  // ... and the canonical bookkeeping of the symbols >= 256 (CanonTables::nl)
 };
 
 // Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).

@@ -111,3 +111,27 @@ if hasattr(Lc, "fdh_debug_s2"):
         d = torch.nonzero(rows_out[sid] != rows_raw[sid]).flatten()
         if d.numel():
             print("  differing bytes: %d, first %d last %d" % (d.numel(), int(d[0]), int(d[-1])))
+if hasattr(Lc, "fdh_debug_s2time"):
+    fd.inflate_batch(comp, t_off, out, r_off, ol, st, ad, flags=0x800)
+    torch.cuda.synchronize()
+    tb = np.zeros(4096 * 16, dtype=np.uint32)
+    Lc.fdh_debug_s2time(tb.ctypes.data_as(C.c_void_p))
+    t = tb.reshape(4096, 16).astype(np.int64)
+    m = min(n, 4096)
+    sel = np.array([i for i in range(m) if i % 16 not in (7, 15)])
+    d = (t[:, 1:6] - t[:, 0:5]) & 0xFFFFFFFF
+    names = ["guess", "tail count", "check", "plan", "write pass"]
+    tot = d[sel].sum(axis=1).mean()
+    print("cycles per noisy stream (lane 0 of its wavefront, clock64): total %.0f" % tot)
+    for k, nm in enumerate(names):
+        print("  %-12s %8.0f  %5.1f %%" % (nm, d[sel, k].mean(), 100 * d[sel, k].mean() / tot))
+    wn = ["round set-up (search, checkpoints, fit)", "", "input image + lane set-up", "groups", "chains", "checks + waiting runs", "flush", "carry"]
+    acc = t[:, 8:16]
+    wtot = acc[sel].sum(axis=1).mean()
+    for k, nm in enumerate(wn):
+        if nm:
+            v = acc[sel, k].mean() + (acc[sel, 1].mean() if k == 0 else 0)
+            print("    write: %-40s %8.0f  %5.1f %%" % (nm, v, 100 * v / wtot))
+    for kind in (7, 15):
+        selk = np.array([i for i in range(m) if i % 16 == kind])
+        print("  kind %d streams: total %.0f cycles (write %.0f)" % (kind, d[selk].sum(axis=1).mean(), d[selk, 4].mean()))
