@@ -503,6 +503,7 @@ extern "C" int fdh_debug_s2(uint32_t* host, uint32_t sid) {  // returns the reco
 extern "C" int fdh_debug_s2time(uint32_t* host) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_s2time), 4096 * 16 * 4);
+    hipMemcpyFromSymbol(host + 4096 * 16, HIP_SYMBOL(fdh::g_s2time2), 4096 * 8 * 4);
     return 0;
 }
 #endif

@@ -75,6 +75,7 @@ __device__ uint32_t g_s2dbg_sid = 0xFFFFFFFFu;
         }                                                                                          \
     } while (0)
 __device__ uint32_t g_s2time[4096 * 16];
+__device__ uint32_t g_s2time2[4096 * 8];
 #define S2T(k) do { if (sid < 4096 && lane == 0) g_s2time[sid * 16 + (k)] = (uint32_t)clock64(); } while (0)
 #define S2ACC_DECL uint32_t s2acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long s2t_ = clock64()
 #define S2ACC(k) do { const long long n_ = clock64(); s2acc_[k] += (uint32_t)(n_ - s2t_); s2t_ = n_; } while (0)
@@ -85,6 +86,16 @@ __device__ uint32_t g_s2time[4096 * 16];
 #define S2ACC_DECL do { } while (0)
 #define S2ACC(k) do { } while (0)
 #define S2ACC_OUT do { } while (0)
+#endif
+
+struct S2Prof {
+    uint32_t acc[8];
+    long long t;
+};
+#ifdef FDH_S2_DEBUG
+#define S2PF(k) do { if (pf) { const long long n_ = clock64(); pf->acc[k] += (uint32_t)(n_ - pf->t); pf->t = n_; } } while (0)
+#else
+#define S2PF(k) do { } while (0)
 #endif
 
 struct Seg2Lds {
@@ -236,7 +247,7 @@ __device__ __forceinline__ void s2_count_general(const uint32_t* lit, const S2Co
         const bool fault = accept && (t.bad || s.pos + t.used > limit);
         bool step = accept && !fault && !t.eob;
         if (!GUESS && rep == 0) {
-            s2_ck_meter(ck, s, step, t.run ? kS2RunCost : 1u);
+            s2_ck_meter(ck, s, step && t.run == 0, 1u);
             step = step && s.stop == 0;
         }
         const bool halt = accept && !step;
@@ -247,11 +258,17 @@ __device__ __forceinline__ void s2_count_general(const uint32_t* lit, const S2Co
         const uint32_t adv = step ? t.used : 0u;
         s.pos += adv;
         rd.advance(adv, nw);
-        go = step && t.run != 0 && s.pos < end;
+        go = step && t.run == 258 && s.pos < end;  // only a flat stretch (258 + 258 + ...) is followed further
     }
     if (!GUESS) {
         s.cnt += chain;
         s.bl += chain >= kS2LongRun ? chain / 16 - 1 : 0u;
+        // a chain ends its interval: the writing pass decodes the literals of an interval in one go and
+        // then, once per round, the chains the lanes have stopped at
+        const bool cut = chain != 0 && s.stop == 0;
+        const bool full = cut && ck.slot >= ck.last;
+        s.stop = full ? 2u : s.stop;
+        s2_ck_store(ck, s, cut && !full);
     }
 }
 
@@ -276,11 +293,15 @@ __device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const S2Codes
 // The long loop of the counting pass: from s.pos until pos >= stop_at (the lane's range ends
 // somewhere inside a group: any symbol boundary will do for the neighbour), every byte counted.
 __device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes& cd, SegReader& rd, uint32_t rb,
-                                             uint32_t limit, bool active, uint32_t stop_at, S2Scan& s, S2Ck& ck) {
+                                             uint32_t limit, bool active, uint32_t stop_at, S2Scan& s, S2Ck& ck,
+                                             S2Prof* pf = nullptr) {
     bool running = active && s.stop == 0 && s.pos < stop_at;
+    S2PF(7);
     if (running) rd.refill_now();
+    S2PF(0);
     while (__any(running)) {
         rd.events(running, kSegEventNeed);
+        S2PF(1);
         // one group per event: 16 look-ups for the lanes that have the input for it (what an event
         // guarantees), or, when no lane has, 8; a lane that cannot take part takes one token
         const bool f2 = running && s.pos + 2 * kSegGroupBits <= limit && rd.level() >= kSegEventNeed;
@@ -291,10 +312,13 @@ __device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes&
         if (__any(fast)) {
             s2_ck_meter(ck, s, fast, 2 * pairs);
             fast = fast && s.stop == 0;
+            S2PF(2);
             if (fast) general = s2_ring_group(pairs, rd, rb, s) == 0;
+            S2PF(3);
         }
         if (__any(general)) s2_count_general<false>(lit, cd, rd, s, ck, general, false, stop_at, limit);
         running = running && s.stop == 0 && s.pos < stop_at;
+        S2PF(4);
     }
 }
 
@@ -413,7 +437,15 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     {
         const bool go = in_range && tail.stop == 0;
         s2_ck_store(tck, tail, go);
+#ifdef FDH_S2_DEBUG
+        S2Prof prof;
+        for (int k_ = 0; k_ < 8; k_++) prof.acc[k_] = 0;
+        prof.t = clock64();
+        s2_tail_scan(lit, cd, rd, rb, limit, go, seg, tail, tck, &prof);
+        if (sid < 4096 && lane == 0) for (int k_ = 0; k_ < 8; k_++) g_s2time2[sid * 8 + k_] = prof.acc[k_];
+#else
         s2_tail_scan(lit, cd, rd, rb, limit, go, seg, tail, tck);
+#endif
     }
 
     S2T(2);
@@ -617,12 +649,22 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
     };
 
     S2ACC_DECL;
-    while (f0 < ni) {
-        S2ACC(0);
-        const uint32_t wq = qa - 16;  // (mod 2^32: the first round starts one piece in front of q = 0)
-        // ---- this lane's interval ----
-        const uint32_t f = f0 + (uint32_t)lane;
-        const bool valid = f < ni;
+    // ---- the rounds are software-pipelined: the checkpoints of the next round are requested before this
+    //      round decodes, its input bytes before this round is flushed ----
+    // per lane: what the lane's interval of a round is
+    struct Slot {
+        uint32_t cbase, bbase, seg_bit0;  // from the owner segment
+        uint2 c0, c1;                     // its two checkpoints
+        bool valid;
+    };
+    struct Ival {
+        uint32_t pos0, pos1, q0, q1, bl0, ib;
+    };
+    // stage A: owner segment of interval fbase + lane, request of its checkpoints
+    auto stage_a = [&](uint32_t fbase) __attribute__((always_inline)) {
+        Slot t;
+        const uint32_t f = fbase + (uint32_t)lane;
+        t.valid = f < ni;
         // owner segment: the last lane whose P <= f (binary search over the lanes' P by ds_bpermute; the
         // lanes without intervals all lie behind the last live lane and have P = ni > f)
         uint32_t sg = 0;
@@ -641,57 +683,89 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const uint32_t k = f - sP;
         const bool in_tail = k >= sHn;
         const uint32_t slot = in_tail ? kS2HeadSlots + (k - sHn) : k;
-        uint2 c0 = make_uint2(0, 0), c1 = make_uint2(0, 0);
-        if (valid) {
-            c0 = ckpt[slot * kWave + sg];
-            c1 = ckpt[(slot + 1) * kWave + sg];
+        t.c0 = t.c1 = make_uint2(0, 0);
+        if (t.valid) {
+            t.c0 = ckpt[slot * kWave + sg];
+            t.c1 = ckpt[(slot + 1) * kWave + sg];
         }
-        const uint32_t cbase = pad0 + sOb + (in_tail ? sHc : 0u);  // virtual offset of the chain part's first byte
-        const uint32_t bbase = sBb + (in_tail ? sHb : 0u);         // bulk lines in front of it
+        t.cbase = pad0 + sOb + (in_tail ? sHc : 0u);  // virtual offset of the chain part's first byte
+        t.bbase = sBb + (in_tail ? sHb : 0u);         // bulk lines in front of it
+        t.seg_bit0 = a.canon_bits + sg * seg;
+        return t;
+    };
+    // stage B: the interval itself
+    auto stage_b = [&](const Slot& t) __attribute__((always_inline)) {
+        Ival v;
         const uint32_t posmask = (1u << kS2PosBits) - 1;
-        const uint32_t seg_bit0 = a.canon_bits + sg * seg;
-        const uint32_t pos0 = seg_bit0 + (c0.x & posmask), pos1 = seg_bit0 + (c1.x & posmask);  // stream bits
-        const uint32_t bl0 = bbase + (c0.x >> kS2PosBits);                                       // bulk lines in front
-        const uint32_t q0 = cbase - 16 * bbase + c0.y, q1 = cbase - 16 * bbase + c1.y;          // image space
+        v.pos0 = t.seg_bit0 + (t.c0.x & posmask);  // stream bits
+        v.pos1 = t.seg_bit0 + (t.c1.x & posmask);
+        v.bl0 = t.bbase + (t.c0.x >> kS2PosBits);  // bulk lines in front
+        v.q0 = t.cbase - 16 * t.bbase + t.c0.y;    // image space
+        v.q1 = t.cbase - 16 * t.bbase + t.c1.y;
+        v.ib = 0;
+        return v;
+    };
+    // the input image of a round: kS2InCap bytes from a0 (16-B aligned), one request per lane and KiB
+    struct InRegs {
+        uint4 v[4];
+    };
+    auto load_input = [&](const uint8_t* a0) __attribute__((always_inline)) {
+        InRegs r;
+        const bool inside = a0 >= buf_lo && a0 + 4096 <= buf_hi;  // (uniform) the usual case: no edge in reach
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
+            const uint8_t* p = a0 + x;
+            r.v[i] = make_uint4(0, 0, 0, 0);
+            if (inside) {
+                if (i < 3 || x < kS2InCap) r.v[i] = *reinterpret_cast<const uint4*>(p);
+            } else if (x < kS2InCap) {
+                const SegChunk ch = seg_load(p, buf_lo, buf_hi);
+                r.v[i] = make_uint4(ch.w[0], ch.w[1], ch.w[2], ch.w[3]);
+            }
+        }
+        return r;
+    };
 
-        // ---- how many intervals fit the images ----
+    Slot slot_cur = stage_a(0);
+    Ival iv = stage_b(slot_cur);
+    bool valid = slot_cur.valid;
+    uint32_t n = 0;
+    const uint8_t* a0 = in;
+    InRegs inr;
+    // fit + input request of the round whose intervals are in iv / valid, for the image base wq_
+    auto stage_c = [&](uint32_t wq_) __attribute__((always_inline)) {
         // input image: from the 16-B line of the first lane's first bit (2 bits in front of its token)
-        const uint8_t* g0 = in + ((pos0 - 2) >> 3);
-        const uint8_t* a0 = reinterpret_cast<const uint8_t*>(uni64(reinterpret_cast<uintptr_t>(g0)) & ~(uintptr_t)15);
-        const uint32_t ib = (uint32_t)(g0 - a0);  // this lane's first byte in the image
-        const bool fits = valid && ib + kS2InReach <= kS2InCap && (q1 - wq) + kS2OutReach <= kS2OutCap;
+        const uint8_t* g0 = in + ((iv.pos0 - 2) >> 3);
+        a0 = reinterpret_cast<const uint8_t*>(uni64(reinterpret_cast<uintptr_t>(g0)) & ~(uintptr_t)15);
+        iv.ib = (uint32_t)(g0 - a0);  // this lane's first byte in the image
+        const bool fits = valid && iv.ib + kS2InReach <= kS2InCap && (iv.q1 - wq_) + kS2OutReach <= kS2OutCap;
         const uint64_t fit_mask = __ballot(fits);
-        const uint32_t n = fit_mask == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fit_mask);
+        n = fit_mask == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fit_mask);
+        inr = load_input(a0);
+    };
+    stage_c(qa - 16);
+    while (f0 < ni) {
+        S2ACC(0);
+        const uint32_t wq = qa - 16;  // (mod 2^32: the first round starts one piece in front of q = 0)
         if (n == 0) {  // cannot happen (one interval always fits); never loop for ever
             bad = true;
             break;
         }
         const bool act = (uint32_t)lane < n;
+        const uint32_t pos0 = iv.pos0, pos1 = iv.pos1, q0 = iv.q0, q1 = iv.q1, bl0 = iv.bl0, ib = iv.ib;
+        const uint8_t* const a0_cur = a0;
+        (void)q1;
         S2ACC(1);
-
-        // ---- input image: kS2InCap bytes from a0, coalesced ----
-        {
-            uint4 v[4];
+        // ---- input image (requested a round ago) ----
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
-                const uint8_t* p = a0 + x;
-                v[i] = make_uint4(0, 0, 0, 0);
-                if (x < kS2InCap) {
-                    if (p >= buf_lo && p + 16 <= buf_hi) {
-                        v[i] = *reinterpret_cast<const uint4*>(p);
-                    } else {
-                        const SegChunk ch = seg_load_edge(p, buf_lo, buf_hi);
-                        v[i] = make_uint4(ch.w[0], ch.w[1], ch.w[2], ch.w[3]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
-                if (x < kS2InCap) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(imgA) + x) = v[i];
-            }
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
+            if (x < kS2InCap) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(imgA) + x) = inr.v[i];
         }
+        // ---- the checkpoints of the next round are on their way while this one decodes ----
+        const uint32_t qf_new = __builtin_amdgcn_readlane(iv.q1, (int)(n - 1));  // image-space end of this round
+        const Slot slot_next = stage_a(f0 + n);
         wave_sync();
         // ---- lane set-up ----
         S2Flat rd;
@@ -703,92 +777,76 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const uint32_t oaddr0 = ldsB + (q0 - wq);
         uint32_t oaddr = oaddr0;  // LDS address of the lane's next output byte
         uint32_t acc = 0;
-        uint32_t bl_here = bl0;   // bulk lines in front of the lane's position
-        // runs whose byte in front is not in the image yet (a run at the very start of an interval, or
-        // right behind such a run) wait for the end of the round: one per half
-        uint32_t def_len[4] = {0, 0, 0, 0}, def_addr[4] = {0, 0, 0, 0}, def_bl[4] = {0, 0, 0, 0};
-        uint32_t def_end = oaddr0;  // a chain that starts here must wait
         S2ACC(2);
 
-        // ---- four halves: a group of look-ups, then the run chains the lanes stopped at ----
-#pragma unroll
-        for (int half = 0; half < 4; half++) {
-            uint32_t e = 1;
-            if (act) {
-                uint32_t c = rd.boff | (oaddr << 6);
-                uint32_t ra = ldsA + 4 * rd.wi;
-                const uint32_t ra0 = ra;
-                e = seg2_write_group(kS2Pairs, rd.lo, rd.hi, c, ra, acc);
-                rd.wi += (ra - ra0) >> 2;
-                rd.boff = c & 63u;
-                oaddr = c >> 6;
-            }
-            S2ACC(3);
-            // stream bit of the lane's next token
-            uint32_t pos = 8 * ((uint32_t)(a0 - in) + 4 * (rd.wi - 2)) + rd.boff + 2;
-            bool go = act && e == 0 && pos < pos1;
-            if (__any(go)) {
-                const bool mine = go;
-                uint32_t chain = 0;
-                for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
-                    const uint32_t raw = rd.raw_window();
-                    const uint32_t nw = rd.peek();
-                    const S2Tok t = s2_token(lit, cd, raw, go, false);
-                    // only runs are decoded here; anything else inside the interval contradicts the counting pass
-                    const bool step = go && t.run != 0 && !t.bad;
-                    bad = bad || (go && rep == 0 && !step);
-                    chain += step ? t.run : 0u;
-                    const uint32_t adv = step ? t.used : 0u;
-                    pos += adv;
-                    rd.advance(adv, nw);
-                    go = step && pos < pos1;
-                }
-                const bool have = mine && chain != 0;
-                const bool wait = have && oaddr == def_end;
-                const uint32_t kl_mine = chain >= kS2LongRun ? chain / 16 - 1 : 0u;
-                // the chains of this half whose byte in front is there, lane by lane (uniform parameters)
-                uint64_t todo = __ballot(have && !wait);
-                while (todo) {
-                    const int src = __ffsll((unsigned long long)todo) - 1;
-                    todo &= todo - 1;
-                    const uint32_t u_addr = __builtin_amdgcn_readlane(oaddr, src), u_len = __builtin_amdgcn_readlane(chain, src);
-                    const uint32_t u_bl = __builtin_amdgcn_readlane(bl_here, src);
-                    emit_chain(u_addr, u_len, u_bl, wq);
-                }
-                if (wait) {
-                    def_len[half] = chain;
-                    def_addr[half] = oaddr;
-                    def_bl[half] = bl_here;
-                    def_end = oaddr + chain - 16 * kl_mine;
-                }
-                if (have) {
-                    oaddr += chain - 16 * kl_mine;
-                    bl_here += kl_mine;
-                    acc = 0;
-                }
-            }
-            S2ACC(4);
+        // ---- the literals of the interval: one group of kS2Meter look-ups (a lane whose interval is
+        //      shorter decodes on into the next one; a lane that meets a run stops there) ----
+        if (act) {
+            uint32_t c = rd.boff | (oaddr << 6);
+            uint32_t ra = ldsA + 4 * rd.wi;
+            const uint32_t ra0 = ra;
+            (void)seg2_write_group(kS2Meter / 2, rd.lo, rd.hi, c, ra, acc);
+            rd.wi += (ra - ra0) >> 2;
+            rd.boff = c & 63u;
+            oaddr = c >> 6;
         }
-        // every lane must have reached the end of its interval
-        {
-            const uint32_t pos = 8 * ((uint32_t)(a0 - in) + 4 * (rd.wi - 2)) + rd.boff + 2;
-            bad = bad || (act && pos < pos1);
-        }
-        // ---- the runs that waited, in output order (lane by lane, half by half) ----
-        {
-            uint64_t todo = __ballot(act && (def_len[0] | def_len[1] | def_len[2] | def_len[3]) != 0);
+        S2ACC(3);
+        // ---- the chains: an interval ends behind its run chain, so a lane that is not at the end of its
+        //      interval yet sits on one ----
+        uint32_t pos = 8 * ((uint32_t)(a0_cur - in) + 4 * (rd.wi - 2)) + rd.boff + 2;  // stream bit of the next token
+        bool go = act && pos < pos1;
+        if (__any(go)) {
+            const bool mine = go;
+            uint32_t chain = 0;
+            for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
+                const uint32_t raw = rd.raw_window();
+                const uint32_t nw = rd.peek();
+                const S2Tok t = s2_token(lit, cd, raw, go, false);
+                // only runs are decoded here; anything else inside the interval contradicts the counting pass
+                const bool step = go && t.run != 0 && !t.bad;
+                bad = bad || (go && rep == 0 && !step);
+                chain += step ? t.run : 0u;
+                const uint32_t adv = step ? t.used : 0u;
+                pos += adv;
+                rd.advance(adv, nw);
+                go = step && t.run == 258 && pos < pos1;
+            }
+            bad = bad || (mine && pos != pos1);
+            const bool have = mine && chain != 0;
+            const uint32_t kl_mine = chain >= kS2LongRun ? chain / 16 - 1 : 0u;
+            // Short chains behind a literal of the same lane are filled by their lanes, all at once: the byte
+            // in front is in the image.  A chain with whole lines to leave out, or one at the very start of
+            // its interval (the byte in front belongs to the lane before), is stored by the wavefront, in
+            // output order.
+            const bool simple = have && kl_mine == 0 && oaddr != oaddr0;
+            if (__any(simple)) {
+                wave_sync();
+                const uint32_t xi = simple ? oaddr - ldsB : 16u;  // (the other lanes: an empty range)
+                const uint32_t c4 = (uint32_t)imgB8[xi - 1] * 0x01010101u;
+                const uint32_t end = simple ? xi + chain : 0u;
+                for (uint32_t dw = xi & ~3u; __any(dw < end); dw += 4) {
+                    if (dw < end) {
+                        const uint32_t lo_b = dw < xi ? xi - dw : 0u;
+                        const uint32_t hi_b = dw + 4 > end ? end - dw : 4u;
+                        uint32_t m = hi_b >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi_b)) - 1);
+                        m &= ~((1u << (8 * lo_b)) - 1);
+                        __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(imgB8 + dw), c4 & m, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                wave_sync();
+            }
+            uint64_t todo = __ballot(have && !simple);
             while (todo) {
                 const int src = __ffsll((unsigned long long)todo) - 1;
                 todo &= todo - 1;
-#pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    const uint32_t u_len = __builtin_amdgcn_readlane(def_len[h], src);
-                    const uint32_t u_addr = __builtin_amdgcn_readlane(def_addr[h], src), u_bl = __builtin_amdgcn_readlane(def_bl[h], src);
-                    if (u_len) emit_chain(u_addr, u_len, u_bl, wq);
-                }
+                const uint32_t u_addr = __builtin_amdgcn_readlane(oaddr, src), u_len = __builtin_amdgcn_readlane(chain, src);
+                const uint32_t u_bl = __builtin_amdgcn_readlane(bl0, src);
+                emit_chain(u_addr, u_len, u_bl, wq);
             }
         }
-        S2DBG(3, f0, n, (uint32_t)__ballot(bad), (uint32_t)(__ballot(bad) >> 32), (uint32_t)__ballot(act && (8 * ((uint32_t)(a0 - in) + 4 * (rd.wi - 2)) + rd.boff + 2) < pos1), 0, 0);
+        S2ACC(4);
+        S2DBG(3, f0, n, (uint32_t)__ballot(bad), (uint32_t)(__ballot(bad) >> 32), (uint32_t)__ballot(act && pos < pos1), 0, 0);
         if (__any(bad)) {
             bad = true;
             break;
@@ -796,41 +854,60 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         wave_sync();
         S2ACC(5);
         // ---- flush: whole 128-B lines of the image (everything once the stream ends) ----
-        const uint32_t qf_new = __builtin_amdgcn_readlane(q1, (int)(n - 1));  // image-space end of this round
         const bool final_round = f0 + n >= ni;
         const uint32_t qa_new = final_round ? (qf_new + 15) & ~15u : max(qa, qf_new & ~127u);
         const uint32_t xa_new = qa_new - wq;
+        const uint32_t n_cur = n;
+        // ---- the next round: its intervals, how many of them fit, the request of its input bytes ----
+        iv = stage_b(slot_next);
+        valid = slot_next.valid;
+        if (!final_round) stage_c(qa_new - 16);
         S2DBG(1, f0, n, wq, qa, qf_new, qa_new, n_brk | (bla << 8));
-        for (uint32_t x = 16 + 16 * (uint32_t)lane; x < xa_new; x += 16 * kWave) {
-            uint4 q = *reinterpret_cast<const uint4*>(imgB8 + x);
-            // bulk lines in front of this piece: those in front of qa + the breaks at or below it
-            uint32_t lines = bla;
-            for (uint32_t i = 0; i < n_brk; i++) {
-                // (readlane, not a shuffle: the lane that holds entry i may have left this loop already)
-                const uint32_t bq = __builtin_amdgcn_readlane(brk_q, (int)i), bk = __builtin_amdgcn_readlane(brk_k, (int)i);
-                lines += x >= bq ? bk : 0u;
-            }
-            const uint32_t v = wq + x + 16 * lines;
-            if (v >= pad0 && v + 16 <= vend) {
-                *reinterpret_cast<uint4*>(line0 + v) = q;
-            } else {  // first / last piece of the stream: only its own bytes, stored and summed
-                uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        {
+            // all the pieces of the lane are read first (one trip to the LDS, not one per piece)
+            constexpr int kPieces = (kS2OutCap + 16 * kWave - 1) / (16 * kWave);
+            uint4 qs[kPieces];
 #pragma unroll
-                for (uint32_t kk = 0; kk < 16; kk++) {
-                    const bool inside = v + kk >= pad0 && v + kk < vend;
-                    if (inside) line0[v + kk] = (uint8_t)(w[kk >> 2] >> (8 * (kk & 3)));
-                    if (!inside) w[kk >> 2] &= ~(0xFFu << (8 * (kk & 3)));
-                }
-                q = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int i = 0; i < kPieces; i++) {
+                const uint32_t x = 16 + 16 * (uint32_t)lane + 16 * kWave * i;
+                qs[i] = make_uint4(0, 0, 0, 0);
+                if (x < xa_new) qs[i] = *reinterpret_cast<const uint4*>(imgB8 + x);
             }
-            // Adler-32: sum of bytes, sum of (total - offset) x byte
-            const uint32_t sum = bytesum4(q.x) + bytesum4(q.y) + bytesum4(q.z) + bytesum4(q.w);
-            uint32_t u = bytedot4(q.x, 0x03020100u, 0);
-            u = bytedot4(q.y, 0x07060504u, u);
-            u = bytedot4(q.z, 0x0b0a0908u, u);
-            u = bytedot4(q.w, 0x0f0e0d0cu, u);
-            ad_a += sum;
-            ad_b += ((long long)total - ((long long)v - pad0)) * (long long)sum - (long long)u;
+#pragma unroll
+            for (int i = 0; i < kPieces; i++) {
+                const uint32_t x = 16 + 16 * (uint32_t)lane + 16 * kWave * i;
+                if (x < xa_new) {
+                    uint4 q = qs[i];
+                    // bulk lines in front of this piece: those in front of qa + the breaks at or below it
+                    uint32_t lines = bla;
+                    for (uint32_t b = 0; b < n_brk; b++) {
+                        // (readlane, not a shuffle: the lane that holds entry b may not be active here)
+                        const uint32_t bq = __builtin_amdgcn_readlane(brk_q, (int)b), bk = __builtin_amdgcn_readlane(brk_k, (int)b);
+                        lines += x >= bq ? bk : 0u;
+                    }
+                    const uint32_t v = wq + x + 16 * lines;
+                    if (v >= pad0 && v + 16 <= vend) {
+                        *reinterpret_cast<uint4*>(line0 + v) = q;
+                    } else {  // first / last piece of the stream: only its own bytes, stored and summed
+                        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (uint32_t kk = 0; kk < 16; kk++) {
+                            const bool inside = v + kk >= pad0 && v + kk < vend;
+                            if (inside) line0[v + kk] = (uint8_t)(w[kk >> 2] >> (8 * (kk & 3)));
+                            if (!inside) w[kk >> 2] &= ~(0xFFu << (8 * (kk & 3)));
+                        }
+                        q = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    // Adler-32: sum of bytes, sum of (total - offset) x byte
+                    const uint32_t sum = bytesum4(q.x) + bytesum4(q.y) + bytesum4(q.z) + bytesum4(q.w);
+                    uint32_t u = bytedot4(q.x, 0x03020100u, 0);
+                    u = bytedot4(q.y, 0x07060504u, u);
+                    u = bytedot4(q.z, 0x0b0a0908u, u);
+                    u = bytedot4(q.w, 0x0f0e0d0cu, u);
+                    ad_a += sum;
+                    ad_b += (long long)(int32_t)(total + pad0 - v) * (long long)(int32_t)sum - (long long)u;
+                }
+            }
         }
         S2ACC(6);
         if (!final_round) {
@@ -865,7 +942,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
             wave_sync();
         }
         qa = qa_new;
-        f0 += n;
+        f0 += n_cur;
         S2ACC(7);
     }
     S2ACC_OUT;

@@ -114,9 +114,10 @@ if hasattr(Lc, "fdh_debug_s2"):
 if hasattr(Lc, "fdh_debug_s2time"):
     fd.inflate_batch(comp, t_off, out, r_off, ol, st, ad, flags=0x800)
     torch.cuda.synchronize()
-    tb = np.zeros(4096 * 16, dtype=np.uint32)
+    tb = np.zeros(4096 * 24, dtype=np.uint32)
     Lc.fdh_debug_s2time(tb.ctypes.data_as(C.c_void_p))
-    t = tb.reshape(4096, 16).astype(np.int64)
+    t = tb[:4096 * 16].reshape(4096, 16).astype(np.int64)
+    t2 = tb[4096 * 16:].reshape(4096, 8).astype(np.int64)
     m = min(n, 4096)
     sel = np.array([i for i in range(m) if i % 16 not in (7, 15)])
     d = (t[:, 1:6] - t[:, 0:5]) & 0xFFFFFFFF
@@ -132,6 +133,10 @@ if hasattr(Lc, "fdh_debug_s2time"):
         if nm:
             v = acc[sel, k].mean() + (acc[sel, 1].mean() if k == 0 else 0)
             print("    write: %-40s %8.0f  %5.1f %%" % (nm, v, 100 * v / wtot))
+    tn = ["refill at start", "events", "predicates + meter", "group", "general step", "", "", "(entry)"]
+    for k, nm in enumerate(tn):
+        if nm:
+            print("    tail: %-30s %8.0f" % (nm, t2[sel, k].mean()))
     for kind in (7, 15):
         selk = np.array([i for i in range(m) if i % 16 == kind])
         print("  kind %d streams: total %.0f cycles (write %.0f)" % (kind, d[selk].sum(axis=1).mean(), d[selk, 4].mean()))
