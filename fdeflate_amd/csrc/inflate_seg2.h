@@ -185,15 +185,32 @@ struct S2Scan {
 };
 // Checkpoints of one lane: column `lane` of the wavefront's scratch, one uint2 per slot:
 // x = pos | bulk lines << 17, y = bytes - 16 x bulk lines (the image-space count).
+// (slot-major: the lanes cut their chains at the same time, so a store is 512 contiguous bytes; with
+// one row per lane the stores went to 64 different lines each and the kernel ran 10 % slower)
+#define S2_CK_STRIDE kWave
+#define S2_CK_AT(sg, slot) ((slot) * kWave + (sg))
 struct S2Ck {
-    uint2* col;
+    uint2* row;      // the lane's column of the wavefront's scratch: slot s at row[s * kWave]
     uint32_t slot;   // next slot to write
     uint32_t last;   // last slot this scan may use for a cut (one more is kept for its end)
     uint32_t m;      // look-ups since the last checkpoint
+    // A checkpoint is stored LATE: right before the scan requests its next input.  Loads and stores
+    // share one in-order counter (vmcnt), and the compiler waits for vmcnt(0) before it touches the
+    // requested input -- a store issued after the request would be waited for as well.
+    uint2 pend;
+    uint32_t pend_slot;
+    bool has_pend;
 };
+__device__ __forceinline__ void s2_ck_flush(S2Ck& k) {
+    if (k.has_pend) k.row[k.pend_slot * S2_CK_STRIDE] = k.pend;
+    k.has_pend = false;
+}
 __device__ __forceinline__ void s2_ck_store(S2Ck& k, const S2Scan& s, bool doit) {
     if (doit) {
-        k.col[k.slot * kWave] = make_uint2(s.pos | (s.bl << kS2PosBits), s.cnt - 16 * s.bl);
+        if (k.has_pend) k.row[k.pend_slot * S2_CK_STRIDE] = k.pend;  // (two cuts between two requests: rare)
+        k.pend = make_uint2(s.pos | (s.bl << kS2PosBits), s.cnt - 16 * s.bl);
+        k.pend_slot = k.slot;
+        k.has_pend = true;
         k.slot++;
         k.m = 0;
     }
@@ -277,7 +294,7 @@ __device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const S2Codes
                                               uint32_t limit, bool active, uint32_t window, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < window;
     while (__any(running)) {
-        rd.events(running, kSegEventNeed);
+        rd.event(running);
         for (int half = 0; half < 2; half++) {
             const bool fast = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
             bool general = running && !fast && rd.level() >= 2;
@@ -300,7 +317,12 @@ __device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes&
     if (running) rd.refill_now();
     S2PF(0);
     while (__any(running)) {
+        s2_ck_flush(ck);
+#ifdef FDH_S2_EVENTS
         rd.events(running, kSegEventNeed);
+#else
+        rd.event(running);
+#endif
         S2PF(1);
         // one group per event: 16 look-ups for the lanes that have the input for it (what an event
         // guarantees), or, when no lane has, 8; a lane that cannot take part takes one token
@@ -329,7 +351,8 @@ __device__ __forceinline__ void s2_head_scan(const uint32_t* lit, const S2Codes&
                                              uint32_t rb, uint32_t limit, bool active, uint32_t x0, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < x0;
     while (__any(running)) {
-        rd.events(running, kSegEventNeed);
+        s2_ck_flush(ck);
+        rd.event(running);
         for (int half = 0; half < 2; half++) {
             const bool have = running && rd.level() >= kSegHalfNeed;
             const bool f4 = have && s.pos + kSegGroupBits <= x0;
@@ -418,7 +441,10 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     const uint32_t rb = lds_offset(ring) + 4 * (uint32_t)lane;
 
     S2Ck hck, tck;  // checkpoints of the chain through the window / of the rest
-    hck.col = tck.col = ckpt + lane;
+    hck.row = tck.row = ckpt + (uint32_t)lane;
+    hck.has_pend = tck.has_pend = false;
+    hck.pend = tck.pend = make_uint2(0, 0);
+    hck.pend_slot = tck.pend_slot = 0;
     hck.slot = 0;
     hck.last = kS2HeadSlots - 1;
     tck.slot = kS2HeadSlots;
@@ -467,6 +493,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
             head.cnt = head.bl = head.stop = head.eob_bits = 0;
             hck.slot = 0;
             hck.m = 0;
+            hck.has_pend = false;
             rd.start(in, seg_bit0 + start);
         }
         s2_ck_store(hck, head, need);
@@ -480,6 +507,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
             x0 = head.pos;
             tck.slot = kS2HeadSlots;
             tck.m = 0;
+            tck.has_pend = false;
             s2_ck_store(tck, tail, true);  // (its end is stored below: an empty interval)
         }
         if (__any(redo)) {  // rare: re-count this segment from the landing point (the reader is there)
@@ -489,6 +517,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
                 x0 = head.pos;
                 tck.slot = kS2HeadSlots;
                 tck.m = 0;
+                tck.has_pend = false;
             }
             s2_ck_store(tck, tail, redo);
             s2_tail_scan(lit, cd, rd, rb, limit, redo, seg, tail, tck);
@@ -499,6 +528,8 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     // ---- the ends of both chains are checkpoints too ----
     s2_ck_store(hck, head, in_range);
     s2_ck_store(tck, tail, in_range);
+    s2_ck_flush(hck);
+    s2_ck_flush(tck);
 
     // ---- who is live: lanes up to the first stop on a verified chain ----
     const bool verified = in_range && cur_start == start;
@@ -550,6 +581,20 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     plan.seg = seg;
     S2T(4);
     return true;
+}
+
+// Waits until at most `keep` of the wavefront's vector-memory instructions are outstanding (they
+// complete in order; keep >= 6: waits for nothing that matters here -> everything).
+__device__ __forceinline__ void s2_wait_vm(uint32_t keep) {
+    switch (keep) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
 }
 
 // Flat reader of the writing pass: the lane's position in the input image.
@@ -685,8 +730,8 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const uint32_t slot = in_tail ? kS2HeadSlots + (k - sHn) : k;
         t.c0 = t.c1 = make_uint2(0, 0);
         if (t.valid) {
-            t.c0 = ckpt[slot * kWave + sg];
-            t.c1 = ckpt[(slot + 1) * kWave + sg];
+            t.c0 = ckpt[S2_CK_AT(sg, slot)];
+            t.c1 = ckpt[S2_CK_AT(sg, slot + 1)];
         }
         t.cbase = pad0 + sOb + (in_tail ? sHc : 0u);  // virtual offset of the chain part's first byte
         t.bbase = sBb + (in_tail ? sHb : 0u);         // bulk lines in front of it
@@ -705,26 +750,28 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         v.ib = 0;
         return v;
     };
-    // the input image of a round: kS2InCap bytes from a0 (16-B aligned), one request per lane and KiB
-    struct InRegs {
-        uint4 v[4];
-    };
-    auto load_input = [&](const uint8_t* a0) __attribute__((always_inline)) {
-        InRegs r;
-        const bool inside = a0 >= buf_lo && a0 + 4096 <= buf_hi;  // (uniform) the usual case: no edge in reach
+    // The input image of a round: kS2InCap bytes from a0 (16-B aligned), copied by the memory pipeline
+    // straight into the LDS (no registers, nothing the compiler waits for): 1 KiB per instruction, lane l
+    // -> bytes [16 l, 16 l + 16).  Whoever reads the image first waits with s2_wait_vm.  Near the ends
+    // of the batch buffer the bytes take the ordinary route (zero outside the buffer).
+    auto request_input = [&](const uint8_t* a0) __attribute__((always_inline)) {
+        const bool inside = a0 >= buf_lo && a0 + 4096 <= buf_hi;  // (uniform) the usual case
+        if (inside) {
+            const uint8_t* p = a0 + 16 * (uint32_t)lane;
+            auto* dst = (__attribute__((address_space(3))) uint32_t*)imgA;
+            auto* src = (const __attribute__((address_space(1))) uint32_t*)p;
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
-            const uint8_t* p = a0 + x;
-            r.v[i] = make_uint4(0, 0, 0, 0);
-            if (inside) {
-                if (i < 3 || x < kS2InCap) r.v[i] = *reinterpret_cast<const uint4*>(p);
-            } else if (x < kS2InCap) {
-                const SegChunk ch = seg_load(p, buf_lo, buf_hi);
-                r.v[i] = make_uint4(ch.w[0], ch.w[1], ch.w[2], ch.w[3]);
+            for (int i = 0; i < 4; i++) {
+                const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
+                const SegChunk ch = seg_load(a0 + x, buf_lo, buf_hi);
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(imgA) + x) = make_uint4(ch.w[0], ch.w[1], ch.w[2], ch.w[3]);
             }
         }
-        return r;
     };
 
     Slot slot_cur = stage_a(0);
@@ -732,8 +779,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
     bool valid = slot_cur.valid;
     uint32_t n = 0;
     const uint8_t* a0 = in;
-    InRegs inr;
-    // fit + input request of the round whose intervals are in iv / valid, for the image base wq_
+    // fit of the round whose intervals are in iv / valid, for the image base wq_
     auto stage_c = [&](uint32_t wq_) __attribute__((always_inline)) {
         // input image: from the 16-B line of the first lane's first bit (2 bits in front of its token)
         const uint8_t* g0 = in + ((iv.pos0 - 2) >> 3);
@@ -742,9 +788,11 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const bool fits = valid && iv.ib + kS2InReach <= kS2InCap && (iv.q1 - wq_) + kS2OutReach <= kS2OutCap;
         const uint64_t fit_mask = __ballot(fits);
         n = fit_mask == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fit_mask);
-        inr = load_input(a0);
     };
     stage_c(qa - 16);
+    wave_sync();  // (the counting pass is done with this LDS)
+    request_input(a0);
+    uint32_t stores_behind = 0;  // vector-memory instructions issued after the request of the current input image
     while (f0 < ni) {
         S2ACC(0);
         const uint32_t wq = qa - 16;  // (mod 2^32: the first round starts one piece in front of q = 0)
@@ -757,16 +805,12 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const uint8_t* const a0_cur = a0;
         (void)q1;
         S2ACC(1);
-        // ---- input image (requested a round ago) ----
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
-            if (x < kS2InCap) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(imgA) + x) = inr.v[i];
-        }
+        // ---- input image (requested a round ago): wait for it, but not for the stores issued since ----
+        s2_wait_vm(stores_behind);
+        wave_sync();
         // ---- the checkpoints of the next round are on their way while this one decodes ----
         const uint32_t qf_new = __builtin_amdgcn_readlane(iv.q1, (int)(n - 1));  // image-space end of this round
         const Slot slot_next = stage_a(f0 + n);
-        wave_sync();
         // ---- lane set-up ----
         S2Flat rd;
         rd.img = imgA;
@@ -791,6 +835,9 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
             oaddr = c >> 6;
         }
         S2ACC(3);
+        // ---- the next round's intervals (their checkpoints have had the whole group to arrive, and no store
+        //      has been issued since they were requested) ----
+        const Ival iv_next = stage_b(slot_next);
         // ---- the chains: an interval ends behind its run chain, so a lane that is not at the end of its
         //      interval yet sits on one ----
         uint32_t pos = 8 * ((uint32_t)(a0_cur - in) + 4 * (rd.wi - 2)) + rd.boff + 2;  // stream bit of the next token
@@ -858,10 +905,19 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const uint32_t qa_new = final_round ? (qf_new + 15) & ~15u : max(qa, qf_new & ~127u);
         const uint32_t xa_new = qa_new - wq;
         const uint32_t n_cur = n;
-        // ---- the next round: its intervals, how many of them fit, the request of its input bytes ----
-        iv = stage_b(slot_next);
+        // ---- the next round: how many of its intervals fit, the request of its input bytes (this round is
+        //      done with the input image) ----
+        iv = iv_next;
         valid = slot_next.valid;
-        if (!final_round) stage_c(qa_new - 16);
+        wave_sync();
+        if (!final_round) {
+            stage_c(qa_new - 16);
+            request_input(a0);
+        }
+        // the flush below issues one store instruction per KiB of pieces (the first and the last piece of
+        // a stream take more: then everything is waited for)
+        stores_behind = (wq + 16 < pad0 + 16 || final_round) ? 64u : (xa_new - 16 + 1023) / 1024;
+        S2ACC(1);
         S2DBG(1, f0, n, wq, qa, qf_new, qa_new, n_brk | (bla << 8));
         {
             // all the pieces of the lane are read first (one trip to the LDS, not one per piece)
