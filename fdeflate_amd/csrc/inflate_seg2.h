@@ -196,23 +196,59 @@ struct S2Ck {
     uint32_t m;      // look-ups since the last checkpoint
     // A checkpoint is stored LATE: right before the scan requests its next input.  Loads and stores
     // share one in-order counter (vmcnt), and the compiler waits for vmcnt(0) before it touches the
-    // requested input -- a store issued after the request would be waited for as well.
-    uint2 pend;
-    uint32_t pend_slot;
-    bool has_pend;
+    // requested input -- a store issued after the request would be waited for as well.  A lane cuts at
+    // most twice between two requests (the meter in front of a group, a run chain behind it).
+    uint2 pend0, pend1;
+    uint32_t pend_slot;  // slot of pend0 (pend1: the next one)
+    uint32_t n_pend;
 };
 __device__ __forceinline__ void s2_ck_flush(S2Ck& k) {
-    if (k.has_pend) k.row[k.pend_slot * S2_CK_STRIDE] = k.pend;
-    k.has_pend = false;
+    if (k.n_pend > 0) k.row[k.pend_slot * S2_CK_STRIDE] = k.pend0;
+    if (k.n_pend > 1) k.row[(k.pend_slot + 1) * S2_CK_STRIDE] = k.pend1;
+    k.n_pend = 0;
 }
 __device__ __forceinline__ void s2_ck_store(S2Ck& k, const S2Scan& s, bool doit) {
     if (doit) {
-        if (k.has_pend) k.row[k.pend_slot * S2_CK_STRIDE] = k.pend;  // (two cuts between two requests: rare)
-        k.pend = make_uint2(s.pos | (s.bl << kS2PosBits), s.cnt - 16 * s.bl);
-        k.pend_slot = k.slot;
-        k.has_pend = true;
+        if (k.n_pend > 1) s2_ck_flush(k);  // (cannot happen between two requests; at the end of a scan it may)
+        const uint2 v = make_uint2(s.pos | (s.bl << kS2PosBits), s.cnt - 16 * s.bl);
+        k.pend_slot = k.n_pend ? k.pend_slot : k.slot;
+        k.pend1 = k.n_pend ? v : k.pend1;
+        k.pend0 = k.n_pend ? k.pend0 : v;
+        k.n_pend++;
         k.slot++;
         k.m = 0;
+    }
+}
+// One input event of a counting scan: the pair of chunks requested an event ago goes into the ring
+// (this is where the wavefront waits for memory), THEN the checkpoints cut since are stored, THEN
+// the next pair is requested.
+__device__ __forceinline__ void s2_event(SegReader& rd, S2Ck& ck, bool want) {
+    if (rd.has_a && (uint32_t)kSegInWords - (rd.in_wr - rd.in_rd) >= (uint32_t)(2 * kSegChunk)) {
+        rd.put(rd.pend_a);
+        rd.put(rd.pend_b);
+        rd.has_a = rd.has_b = false;
+    }
+    asm volatile("" ::: "memory");
+    s2_ck_flush(ck);
+    asm volatile("" ::: "memory");
+    if (want && !rd.has_a) {
+        if (rd.gp >= rd.buf_lo && rd.gp + 8 * kSegChunk <= rd.buf_hi) {  // one range check for the pair
+            const uint4 va = *reinterpret_cast<const uint4*>(rd.gp);
+            const uint4 vb = *reinterpret_cast<const uint4*>(rd.gp + 4 * kSegChunk);
+            rd.pend_a.w[0] = va.x;
+            rd.pend_a.w[1] = va.y;
+            rd.pend_a.w[2] = va.z;
+            rd.pend_a.w[3] = va.w;
+            rd.pend_b.w[0] = vb.x;
+            rd.pend_b.w[1] = vb.y;
+            rd.pend_b.w[2] = vb.z;
+            rd.pend_b.w[3] = vb.w;
+        } else {
+            rd.pend_a = seg_load(rd.gp, rd.buf_lo, rd.buf_hi);
+            rd.pend_b = seg_load(rd.gp + 4 * kSegChunk, rd.buf_lo, rd.buf_hi);
+        }
+        rd.gp += 8 * kSegChunk;
+        rd.has_a = rd.has_b = true;
     }
 }
 // Before an action that costs `inc` look-ups: cut the interval here if it would not fit.
@@ -294,7 +330,7 @@ __device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const S2Codes
                                               uint32_t limit, bool active, uint32_t window, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < window;
     while (__any(running)) {
-        rd.event(running);
+        s2_event(rd, ck, running);
         for (int half = 0; half < 2; half++) {
             const bool fast = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
             bool general = running && !fast && rd.level() >= 2;
@@ -317,12 +353,7 @@ __device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes&
     if (running) rd.refill_now();
     S2PF(0);
     while (__any(running)) {
-        s2_ck_flush(ck);
-#ifdef FDH_S2_EVENTS
-        rd.events(running, kSegEventNeed);
-#else
-        rd.event(running);
-#endif
+        s2_event(rd, ck, running);
         S2PF(1);
         // one group per event: 16 look-ups for the lanes that have the input for it (what an event
         // guarantees), or, when no lane has, 8; a lane that cannot take part takes one token
@@ -351,8 +382,7 @@ __device__ __forceinline__ void s2_head_scan(const uint32_t* lit, const S2Codes&
                                              uint32_t rb, uint32_t limit, bool active, uint32_t x0, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < x0;
     while (__any(running)) {
-        s2_ck_flush(ck);
-        rd.event(running);
+        s2_event(rd, ck, running);
         for (int half = 0; half < 2; half++) {
             const bool have = running && rd.level() >= kSegHalfNeed;
             const bool f4 = have && s.pos + kSegGroupBits <= x0;
@@ -442,8 +472,8 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
 
     S2Ck hck, tck;  // checkpoints of the chain through the window / of the rest
     hck.row = tck.row = ckpt + (uint32_t)lane;
-    hck.has_pend = tck.has_pend = false;
-    hck.pend = tck.pend = make_uint2(0, 0);
+    hck.n_pend = tck.n_pend = 0;
+    hck.pend0 = hck.pend1 = tck.pend0 = tck.pend1 = make_uint2(0, 0);
     hck.pend_slot = tck.pend_slot = 0;
     hck.slot = 0;
     hck.last = kS2HeadSlots - 1;
@@ -493,7 +523,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
             head.cnt = head.bl = head.stop = head.eob_bits = 0;
             hck.slot = 0;
             hck.m = 0;
-            hck.has_pend = false;
+            hck.n_pend = 0;
             rd.start(in, seg_bit0 + start);
         }
         s2_ck_store(hck, head, need);
@@ -507,7 +537,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
             x0 = head.pos;
             tck.slot = kS2HeadSlots;
             tck.m = 0;
-            tck.has_pend = false;
+            tck.n_pend = 0;
             s2_ck_store(tck, tail, true);  // (its end is stored below: an empty interval)
         }
         if (__any(redo)) {  // rare: re-count this segment from the landing point (the reader is there)
@@ -517,7 +547,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
                 x0 = head.pos;
                 tck.slot = kS2HeadSlots;
                 tck.m = 0;
-                tck.has_pend = false;
+                tck.n_pend = 0;
             }
             s2_ck_store(tck, tail, redo);
             s2_tail_scan(lit, cd, rd, rb, limit, redo, seg, tail, tck);
