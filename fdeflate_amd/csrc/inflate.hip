@@ -113,10 +113,8 @@ struct GeneralLds {
 };
 
 // General kernel: workgroup = one wavefront = one stream, private decode tables in LDS.
-__global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs a) {
-    __shared__ GeneralLds lds;
+__device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLds& lds, const uint64_t sid) {
     const int lane = threadIdx.x;
-    const uint64_t sid = blockIdx.x;
     if (sid >= a.n) return;
     bool tiles = !(a.flags & 2u);
     if (a.only_pending) {
@@ -157,6 +155,18 @@ __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs
         if (a.adler) a.adler[sid] = r.adler;
     }
 }
+__global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs a) {
+    __shared__ GeneralLds lds;
+    if (a.list) {  // only the streams a kernel in front has listed as left over (a grid-stride loop over the list)
+        const uint32_t cnt = a.list[0];
+        for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+            general_one(a, lds, a.list[4 + i]);
+            wave_sync();
+        }
+        return;
+    }
+    general_one(a, lds, blockIdx.x);
+}
 
 // Fast general kernel: the same decoder with an 8-bit literal/length table (1 KiB instead of 16 KiB)
 // and at most 128 VGPRs (20 of them spilled): 9.9 KiB of LDS per stream with the 2 KiB output ring,
@@ -177,10 +187,8 @@ struct GeneralFastLds {
 };
 static_assert(sizeof(HeaderScratch) <= sizeof(WaveIo::mlist) && offsetof(WaveIo, mlist) % 16 == 0,
               "the header scratch must fit the match list it shares LDS with");
-__global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_general_fast_kernel(InflateBatchArgs a) {
-    __shared__ GeneralFastLds lds;
+__device__ __forceinline__ void general_fast_one(const InflateBatchArgs& a, GeneralFastLds& lds, const uint64_t sid) {
     const int lane = threadIdx.x;
-    const uint64_t sid = blockIdx.x;
     if (sid >= a.n) return;
     if (a.only_pending && a.status[sid] != kPending) return;
     const StreamArgs s = stream_args(a, sid);
@@ -196,6 +204,18 @@ __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_genera
             if (a.adler) a.adler[sid] = r.adler;
         }
     }
+}
+__global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_general_fast_kernel(InflateBatchArgs a) {
+    __shared__ GeneralFastLds lds;
+    if (a.list) {
+        const uint32_t cnt = a.list[0];
+        for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+            general_fast_one(a, lds, a.list[4 + i]);
+            wave_sync();
+        }
+        return;
+    }
+    general_fast_one(a, lds, blockIdx.x);
 }
 
 struct CanonLds {
@@ -287,6 +307,7 @@ __global__ __launch_bounds__(kLaneBlock) void inflate_lanes_kernel(LaneArgs a) {
 // (inflate_segments.h).
 __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(SegArgs a) {
     __shared__ SegLds lds;
+    if (a.src_list && a.src_list[0] == 0) return;  // the interval kernel left nothing over: do not even stage the table
     // the hand-scheduled loops address the table from LDS offset 0 (`raw & 0x3ffc` IS the address)
     if (lds_offset(lds.lit) != 0) __builtin_trap();
     // stage the table in this kernel's entry layout (up to three literals per entry), built from the
@@ -625,16 +646,20 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             unsigned cblocks = (unsigned)((n + fdh::kCanonWaves - 1) / fdh::kCanonWaves);
             hipLaunchKernelGGL(fdh::inflate_canon_kernel, dim3(cblocks), dim3(fdh::kCanonWaves * fdh::kWave), 0, stream, a);
             e = hipGetLastError();
+            // the general kernels walk the same list (what the canon kernel finished is no longer PENDING):
+            // a grid-stride loop, so a batch that is all canonical costs two near-empty launches
+            const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 8192);
+            if (e == hipSuccess && !(flags & 0x200u)) {
+                hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3(gblocks), dim3(fdh::kWave), 0, stream, a);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3(gblocks), dim3(fdh::kWave), 0, stream, a);
+                e = hipGetLastError();
+            }
             a.list = nullptr;
             (void)hipFreeAsync(list, stream);
-            if (e != hipSuccess) return (int)e;
-            if (!(flags & 0x200u)) {
-                hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
-                e = hipGetLastError();
-                if (e != hipSuccess) return (int)e;
-            }
-            hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
-            return (int)hipGetLastError();
+            return (int)e;
         }
     }
     // Dense batches first go through the stream-per-lane kernel; it finishes the canonical

@@ -614,7 +614,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
 }
 
 // Waits until at most `keep` of the wavefront's vector-memory instructions are outstanding (they
-// complete in order; keep >= 6: waits for nothing that matters here -> everything).
+// complete in order; keep >= 8: everything).
 __device__ __forceinline__ void s2_wait_vm(uint32_t keep) {
     switch (keep) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -623,6 +623,8 @@ __device__ __forceinline__ void s2_wait_vm(uint32_t keep) {
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -835,12 +837,13 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const uint8_t* const a0_cur = a0;
         (void)q1;
         S2ACC(1);
-        // ---- input image (requested a round ago): wait for it, but not for the stores issued since ----
-        s2_wait_vm(stores_behind);
-        wave_sync();
         // ---- the checkpoints of the next round are on their way while this one decodes ----
         const uint32_t qf_new = __builtin_amdgcn_readlane(iv.q1, (int)(n - 1));  // image-space end of this round
         const Slot slot_next = stage_a(f0 + n);
+        // ---- input image (requested a round ago): wait for it, but not for what was issued since (the
+        //      stores of the flush and the two requests just made) ----
+        s2_wait_vm(stores_behind + (f0 + n < ni ? 2u : 0u));
+        wave_sync();
         // ---- lane set-up ----
         S2Flat rd;
         rd.img = imgA;
