@@ -329,8 +329,8 @@ def roofline(alg_bytes, kern_ms, kernel, traffic):
             "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
 
-DECODE_KERNELS = ("inflate_segments_kernel (+ inflate_canon_kernel / inflate_general_fast_kernel / "
-                  "inflate_general_kernel follow-ups, one fdh_inflate_batch launch)")
+DECODE_KERNELS = ("inflate_seg2_kernel (+ inflate_segments_kernel / inflate_canon_kernel / inflate_general_fast_kernel / "
+                  "inflate_general_kernel follow-ups on what it leaves over, one fdh_inflate_batch call)")
 
 
 def main():

@@ -66,6 +66,7 @@ def lib():
     L.fdh_init.argtypes = [u64]
     L.fdh_shutdown.restype = C.c_int
     L.fdh_multi_device_count.restype = C.c_int
+    L.fdh_multi_uses_rccl.restype = C.c_int
     L.fdh_inflate_batch_multi.restype = C.c_int
     L.fdh_inflate_batch_multi.argtypes = [vp, u32, u32, u64]
     L.fdh_compress_bound.restype = u64
@@ -99,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "fdh_decompressor_is_done", "fdh_decompressor_read",
     "fdh_compress_bound", "fdh_deflate_general_batch", "fdh_compress_to_vec", "fdh_compress_to_vec_rle",
     "fdh_png_unfilter_batch", "fdh_png_filter_batch", "fdh_inflate_png_batch",
-    "fdh_init", "fdh_shutdown", "fdh_multi_device_count", "fdh_inflate_batch_multi",
+    "fdh_init", "fdh_shutdown", "fdh_multi_device_count", "fdh_multi_uses_rccl", "fdh_inflate_batch_multi",
 ]
 
 

@@ -363,6 +363,11 @@ def init_devices(mask=0):
     return _lib.lib().fdh_multi_device_count()
 
 
+def multi_uses_rccl():
+    """True if inflate_batch_multi gathers through RCCL (more than one device, or FDH_MULTI_FORCE_RCCL=1)."""
+    return bool(_lib.lib().fdh_multi_uses_rccl())
+
+
 def shutdown_devices():
     _lib.check(_lib.lib().fdh_shutdown())
 

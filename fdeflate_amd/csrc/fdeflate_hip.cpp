@@ -27,8 +27,8 @@ int fdh_launch_deflate_general(const uint8_t* in, const uint64_t* in_off, uint8_
                                uint32_t* out_len, uint64_t n, int rle, void* hash, void* matches, void* blocks,
                                uint32_t* nblocks, unsigned waves, unsigned lanes, hipStream_t stream);
 int fdh_launch_png_unfilter(const uint8_t* filt, const uint64_t* filt_off, uint8_t* pix, const uint64_t* pix_off,
-                            uint32_t* status, const uint32_t* gate, uint64_t n, uint32_t row_bytes, uint32_t bpp,
-                            hipStream_t stream);
+                            uint32_t* status, const uint32_t* gate, const uint32_t* gate_len, uint64_t n,
+                            uint32_t row_bytes, uint32_t bpp, hipStream_t stream);
 int fdh_launch_png_filter(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types, const uint64_t* types_off,
                           uint8_t* filt, const uint64_t* filt_off, uint32_t* status, uint64_t n, uint32_t row_bytes,
                           uint32_t bpp, hipStream_t stream);
@@ -188,7 +188,7 @@ int fdh_png_unfilter_batch(const uint8_t* filt, const uint64_t* filt_off, uint8_
     if (n == 0) return FDH_SUCCESS;
     int rc = png_args_ok(filt, filt_off, pix, pix_off, png_status, row_bytes, bpp);
     if (rc != FDH_SUCCESS) return rc;
-    rc = fdh_launch_png_unfilter(filt, filt_off, pix, pix_off, png_status, nullptr, n, row_bytes, bpp,
+    rc = fdh_launch_png_unfilter(filt, filt_off, pix, pix_off, png_status, nullptr, nullptr, n, row_bytes, bpp,
                                  static_cast<hipStream_t>(hip_stream));
     if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "unfilter kernel launch");
     return FDH_SUCCESS;
@@ -217,8 +217,10 @@ int fdh_inflate_png_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* fi
     rc = fdh_inflate_batch(in, in_off, filt, filt_off, out_len, status, adler, n, flags, hip_stream);
     if (rc != FDH_SUCCESS) return rc;
     // same stream: the scanlines are reconstructed as soon as the decode kernels have finished, only
-    // for the streams that decoded (status 0) -- the rest gets png_status 3
-    rc = fdh_launch_png_unfilter(filt, filt_off, pix, pix_off, png_status, status, n, row_bytes, bpp,
+    // for the streams that decoded (status 0) -- the rest gets png_status 3 -- and that decoded to
+    // exactly the bytes of their slot: a stream that ends early would leave stale bytes behind it
+    // (png_status 2; the png crate treats short IDAT data as an error as well)
+    rc = fdh_launch_png_unfilter(filt, filt_off, pix, pix_off, png_status, status, out_len, n, row_bytes, bpp,
                                  static_cast<hipStream_t>(hip_stream));
     if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "unfilter kernel launch");
     return FDH_SUCCESS;

@@ -4,7 +4,10 @@
 // stream.  The only collective is the all-gather of the fixed-size per-stream results
 // {status, out_len, adler} (12 B per stream) over RCCL (xGMI), so that every device -- and through
 // it the caller -- sees the status of the whole batch.  RCCL is loaded lazily (dlopen) and only
-// when more than one device takes part; with one device the "gather" is a device-to-device copy.
+// when more than one device takes part; with one device the "gather" is a device-to-device copy
+// (FDH_MULTI_FORCE_RCCL=1 makes a single device go through RCCL as well: a one-rank communicator,
+// the same ncclGroupStart / ncclAllGather / ncclGroupEnd calls -- the way to exercise that path on
+// a one-GPU box).
 //
 // (The Python layer has the one-process-per-GPU form of the same thing: fdeflate_amd/distributed.py
 // over torch.distributed, which is what bench.py uses.)
@@ -13,6 +16,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -42,6 +46,7 @@ struct Multi {
     p_ncclAllGather AllGather = nullptr;
     p_ncclGroup GroupStart = nullptr, GroupEnd = nullptr;
     p_ncclGetErrorString GetErrorString = nullptr;
+    bool use_rccl = false;  // more than one device, or forced
     bool ready = false;
 };
 Multi g_multi;
@@ -77,7 +82,15 @@ extern "C" {
 
 int fdh_init(uint64_t device_mask) {
     std::lock_guard<std::mutex> lock(g_multi_mutex);
-    if (g_multi.ready) release_locked();
+    // whatever an earlier call left behind -- a complete state or the debris of a failed attempt --
+    // goes first; and every error path below releases what this call has built
+    release_locked();
+    struct Guard {
+        bool armed = true;
+        ~Guard() {
+            if (armed) release_locked();
+        }
+    } guard;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
@@ -94,33 +107,27 @@ int fdh_init(uint64_t device_mask) {
         HIP_TRY(hipSetDevice(m.devices[i]));
         HIP_TRY(hipStreamCreateWithFlags(&m.streams[i], hipStreamNonBlocking));
     }
-    if (m.devices.size() > 1) {
+    const char* force = std::getenv("FDH_MULTI_FORCE_RCCL");
+    m.use_rccl = m.devices.size() > 1 || (force && force[0] == '1');
+    if (m.use_rccl) {
         m.rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!m.rccl) m.rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!m.rccl) {
-            release_locked();
-            return fail(FDH_ERR_HIP, "librccl.so could not be loaded (needed for more than one device)");
-        }
+        if (!m.rccl) return fail(FDH_ERR_HIP, "librccl.so could not be loaded (needed for more than one device)");
         m.CommInitAll = (p_ncclCommInitAll)dlsym(m.rccl, "ncclCommInitAll");
         m.CommDestroy = (p_ncclCommDestroy)dlsym(m.rccl, "ncclCommDestroy");
         m.AllGather = (p_ncclAllGather)dlsym(m.rccl, "ncclAllGather");
         m.GroupStart = (p_ncclGroup)dlsym(m.rccl, "ncclGroupStart");
         m.GroupEnd = (p_ncclGroup)dlsym(m.rccl, "ncclGroupEnd");
         m.GetErrorString = (p_ncclGetErrorString)dlsym(m.rccl, "ncclGetErrorString");
-        if (!m.CommInitAll || !m.CommDestroy || !m.AllGather || !m.GroupStart || !m.GroupEnd) {
-            release_locked();
+        if (!m.CommInitAll || !m.CommDestroy || !m.AllGather || !m.GroupStart || !m.GroupEnd)
             return fail(FDH_ERR_HIP, "librccl.so lacks an expected entry point");
-        }
         m.comms.assign(m.devices.size(), nullptr);
         int rc = m.CommInitAll(m.comms.data(), (int)m.devices.size(), m.devices.data());
-        if (rc != 0) {
-            std::string why = m.GetErrorString ? m.GetErrorString(rc) : "error";
-            release_locked();
-            return fail(FDH_ERR_HIP, "ncclCommInitAll: " + why);
-        }
+        if (rc != 0) return fail(FDH_ERR_HIP, std::string("ncclCommInitAll: ") + (m.GetErrorString ? m.GetErrorString(rc) : "error"));
     }
     (void)hipSetDevice(prev);
     m.ready = true;
+    guard.armed = false;
     return FDH_SUCCESS;
 }
 
@@ -136,6 +143,11 @@ int fdh_shutdown(void) {
 int fdh_multi_device_count(void) {
     std::lock_guard<std::mutex> lock(g_multi_mutex);
     return g_multi.ready ? (int)g_multi.devices.size() : 0;
+}
+
+int fdh_multi_uses_rccl(void) {
+    std::lock_guard<std::mutex> lock(g_multi_mutex);
+    return (g_multi.ready && g_multi.use_rccl) ? 1 : 0;
 }
 
 int fdh_inflate_batch_multi(const fdh_shard_t* shards, uint32_t n_shards, uint32_t flags, uint64_t meta_stride) {
@@ -156,12 +168,26 @@ int fdh_inflate_batch_multi(const fdh_shard_t* shards, uint32_t n_shards, uint32
     }
     int prev = 0;
     HIP_TRY(hipGetDevice(&prev));
+    // on every way out: the shards already launched are waited for (an error must not return while
+    // other devices still write the caller's buffers), then the caller's device is restored
     struct Back {
         int dev;
-        ~Back() { (void)hipSetDevice(dev); }
-    } back{prev};
+        Multi* m;
+        uint32_t launched = 0;
+        bool done = false;
+        ~Back() {
+            if (!done) {
+                for (uint32_t i = 0; i < launched; i++) {
+                    (void)hipSetDevice(m->devices[i]);
+                    (void)hipStreamSynchronize(m->streams[i]);
+                }
+            }
+            (void)hipSetDevice(dev);
+        }
+    } back{prev, &m};
     // staging for the gather: {status, out_len, adler} of the shard, padded to meta_stride
     if (gather && m.cap < meta_stride) {
+        m.cap = 0;  // (a failed allocation below must not leave a stale capacity behind)
         for (size_t i = 0; i < m.devices.size(); i++) {
             HIP_TRY(hipSetDevice(m.devices[i]));
             if (m.meta_send[i]) (void)hipFree(m.meta_send[i]);
@@ -174,6 +200,7 @@ int fdh_inflate_batch_multi(const fdh_shard_t* shards, uint32_t n_shards, uint32
     for (uint32_t i = 0; i < n_shards; i++) {
         const fdh_shard_t& s = shards[i];
         HIP_TRY(hipSetDevice(m.devices[i]));
+        back.launched = i + 1;
         int rc = fdh_inflate_batch(s.in, s.in_off, s.out, s.out_off, s.out_len, s.status, s.adler, s.n, flags, m.streams[i]);
         if (rc != FDH_SUCCESS) return rc;
         if (gather) {
@@ -189,7 +216,7 @@ int fdh_inflate_batch_multi(const fdh_shard_t* shards, uint32_t n_shards, uint32
     // 2. the one collective: all-gather of the per-stream results (12 B per stream) over RCCL
     if (gather) {
         const size_t count = 3 * meta_stride;
-        if (n_shards == 1) {
+        if (!m.use_rccl) {
             HIP_TRY(hipSetDevice(m.devices[0]));
             HIP_TRY(hipMemcpyAsync(shards[0].meta_all, m.meta_send[0], count * 4, hipMemcpyDeviceToDevice, m.streams[0]));
         } else {
@@ -208,6 +235,7 @@ int fdh_inflate_batch_multi(const fdh_shard_t* shards, uint32_t n_shards, uint32
         HIP_TRY(hipSetDevice(m.devices[i]));
         HIP_TRY(hipStreamSynchronize(m.streams[i]));
     }
+    back.done = true;
     return FDH_SUCCESS;
 }
 

@@ -32,6 +32,8 @@ struct PngArgs {
     const uint64_t* types_off;  // filter only: n + 1
     uint32_t* status;         // 0 ok, 1 filter type > 4, 2 sizes do not fit, 3 skipped (gate)
     const uint32_t* gate;     // nullable: image i is processed only if gate[i] == 0 (the decoder's status)
+    const uint32_t* gate_len; // nullable (with gate): ... and gate_len[i] (the decoded length) fills the source slot
+                              // exactly: a stream that ends early leaves stale bytes behind it -> status 2
     uint64_t n;
     uint32_t row_bytes;
 };
@@ -130,12 +132,20 @@ __device__ __forceinline__ void png_row(const uint8_t* in, const uint8_t* up, ui
     }
 }
 
+// 0: process image i; 3: its stream did not decode; 2: it decoded to fewer bytes than the slot holds
+__device__ __forceinline__ uint32_t png_gate(const PngArgs& a, uint64_t i) {
+    if (!a.gate) return 0;
+    if (a.gate[i] != 0) return 3;
+    if (a.gate_len && (uint64_t)a.gate_len[i] != a.src_off[i + 1] - a.src_off[i]) return 2;
+    return 0;
+}
+
 template <int BPP, bool UNFILTER>
 __global__ __launch_bounds__(kWave) void png_filter_kernel(PngArgs a) {
     const uint64_t i = (uint64_t)blockIdx.x * kWave + threadIdx.x;
     if (i >= a.n) return;
-    if (a.gate && a.gate[i] != 0) {
-        a.status[i] = 3;
+    if (const uint32_t g = png_gate(a, i)) {
+        a.status[i] = g;
         return;
     }
     const uint64_t s0 = a.src_off[i], s1 = a.src_off[i + 1], d0 = a.dst_off[i], d1 = a.dst_off[i + 1];
@@ -213,8 +223,8 @@ __global__ __launch_bounds__(kWave) void png_wave_kernel(PngArgs a) {
     __shared__ PngWaveLds lds;
     const uint64_t i = blockIdx.x;
     const uint32_t lane = threadIdx.x;
-    if (a.gate && a.gate[i] != 0) {
-        if (lane == 0) a.status[i] = 3;
+    if (const uint32_t g = png_gate(a, i)) {
+        if (lane == 0) a.status[i] = g;
         return;
     }
     const uint64_t s0 = a.src_off[i], s1 = a.src_off[i + 1], d0 = a.dst_off[i], d1 = a.dst_off[i + 1];
@@ -361,8 +371,8 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
     uint32_t my_rows = 0, my_st = 0;
     if (lane < cnt) {
         const uint64_t i = img0 + lane;
-        if (a.gate && a.gate[i] != 0) {
-            my_st = 3;
+        if (const uint32_t g = png_gate(a, i)) {
+            my_st = g;
         } else {
             const uint64_t fl = a.src_off[i + 1] - a.src_off[i], pl = a.dst_off[i + 1] - a.dst_off[i];
             const uint64_t rows = fl / (rb + 1);
@@ -556,15 +566,15 @@ static int png_launch(const fdh::PngArgs& a, uint32_t bpp, hipStream_t stream) {
 }
 
 extern "C" int fdh_launch_png_unfilter(const uint8_t* filt, const uint64_t* filt_off, uint8_t* pix, const uint64_t* pix_off,
-                                       uint32_t* status, const uint32_t* gate, uint64_t n, uint32_t row_bytes, uint32_t bpp,
-                                       hipStream_t stream) {
-    fdh::PngArgs a{filt, filt_off, pix, pix_off, nullptr, nullptr, status, gate, n, row_bytes};
+                                       uint32_t* status, const uint32_t* gate, const uint32_t* gate_len, uint64_t n,
+                                       uint32_t row_bytes, uint32_t bpp, hipStream_t stream) {
+    fdh::PngArgs a{filt, filt_off, pix, pix_off, nullptr, nullptr, status, gate, gate_len, n, row_bytes};
     return png_launch<true>(a, bpp, stream);
 }
 
 extern "C" int fdh_launch_png_filter(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types,
                                      const uint64_t* types_off, uint8_t* filt, const uint64_t* filt_off, uint32_t* status,
                                      uint64_t n, uint32_t row_bytes, uint32_t bpp, hipStream_t stream) {
-    fdh::PngArgs a{pix, pix_off, filt, filt_off, types, types_off, status, nullptr, n, row_bytes};
+    fdh::PngArgs a{pix, pix_off, filt, filt_off, types, types_off, status, nullptr, nullptr, n, row_bytes};
     return png_launch<false>(a, bpp, stream);
 }

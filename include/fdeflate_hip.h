@@ -161,8 +161,9 @@ uint64_t fdh_compress_bound(uint64_t len);
  *                           into `types`, one byte per row)
  *   fdh_inflate_png_batch   fdh_inflate_batch into `filt` (the slots must be the exact image sizes)
  *                           followed, on the same stream, by the reconstruction into `pix` of every
- *                           stream that decoded
- * png_status[i]: 0 ok, 1 a filter type > 4, 2 sizes do not fit, 3 skipped (stream did not decode). */
+ *                           stream that decoded to exactly the bytes of its slot
+ * png_status[i]: 0 ok, 1 a filter type > 4, 2 sizes do not fit (fdh_inflate_png_batch: also a stream
+ * that ended before its slot was full -- short IDAT data), 3 skipped (stream did not decode). */
 int fdh_png_unfilter_batch(const uint8_t *filt, const uint64_t *filt_off, uint8_t *pix,
                            const uint64_t *pix_off, uint32_t *png_status, uint64_t n,
                            uint32_t row_bytes, uint32_t bpp, void *hip_stream);
@@ -253,6 +254,9 @@ typedef struct fdh_shard {
 int fdh_init(uint64_t device_mask);
 int fdh_shutdown(void);
 int fdh_multi_device_count(void); /* devices selected by the last fdh_init, 0 before */
+int fdh_multi_uses_rccl(void);    /* 1 if the gather goes through RCCL: more than one device, or
+                                     FDH_MULTI_FORCE_RCCL=1 in the environment of fdh_init (a one-rank
+                                     communicator: the way to run that path on a one-GPU box) */
 int fdh_inflate_batch_multi(const fdh_shard_t *shards, uint32_t n_shards, uint32_t flags,
                             uint64_t meta_stride);
 

@@ -685,12 +685,19 @@ def test_general_encoder_roundtrip_at_scale(harness):
         del comp, out
 
 
-def test_multi_gpu_entry_points_every_visible_device(harness):
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_multi_gpu_entry_points_every_visible_device(harness, force_rccl, monkeypatch):
     """fdh_init / fdh_inflate_batch_multi / fdh_shutdown: the mixed batch sharded by contiguous
     ranges over every visible GPU from ONE process, results all-gathered (RCCL when more than one
-    device takes part), compared stream by stream with the oracle."""
+    device takes part, or -- second run -- forced: a one-rank communicator on a one-GPU box, so
+    that ncclCommInitAll / ncclGroupStart / ncclAllGather / ncclGroupEnd of csrc/multi_gpu.cpp
+    actually execute), compared stream by stream with the oracle."""
     import torch
     import fdeflate_amd as fd
+    if force_rccl:
+        monkeypatch.setenv("FDH_MULTI_FORCE_RCCL", "1")
+    else:
+        monkeypatch.delenv("FDH_MULTI_FORCE_RCCL", raising=False)
     pool = []
     for name, comp, raw in streams.valid_streams():
         pool.append((comp, len(raw)))
@@ -701,6 +708,9 @@ def test_multi_gpu_entry_points_every_visible_device(harness):
     g = fd.init_devices(0)
     try:
         assert g == torch.cuda.device_count() >= 1
+        assert fd.multi_uses_rccl() == (force_rccl or g > 1)
+        if fd.multi_uses_rccl():   # librccl is mapped into this process
+            assert "librccl" in open("/proc/self/maps").read()
         per = (len(pool) + g - 1) // g
         shards, expect = [], []
         for k in range(g):
@@ -820,6 +830,9 @@ def test_png_filters_bit_exact_and_fused_decode(harness):
             filt_imgs = [synth.gen_stream_np(i, rows * (rb + 1)).tobytes() for i in range(n)]   # type byte 0..4 per row
             comps = [ob.compress_ultra_fast(f) for f in filt_imgs]
             comps[5] = comps[5][:-9]
+            # a VALID stream that ends before its slot is full (short IDAT data): decodes fine, but
+            # the rest of the slot holds stale bytes -- it must not be reconstructed (png_status 2)
+            comps[9] = ob.compress_ultra_fast(filt_imgs[9][:rows * (rb + 1) - (rb + 1)])
             cbuf, coff = streams.pack_exact(comps)
             foff = np.arange(n + 1, dtype=np.int64) * (rows * (rb + 1))
             poff = np.arange(n + 1, dtype=np.int64) * (rows * rb)
@@ -832,6 +845,10 @@ def test_png_filters_bit_exact_and_fused_decode(harness):
             for i in range(n):
                 if i == 5:
                     assert stl[i] == 2 and psl[i] == 3
+                    continue
+                if i == 9:
+                    assert stl[i] == 0 and int(out_len[i]) == (rows - 1) * (rb + 1) and psl[i] == 2
+                    assert not hp[poff[i]:poff[i + 1]].any()   # nothing written
                     continue
                 est, epix = ob.png_unfilter(filt_imgs[i], rb, bpp)
                 assert stl[i] == 0 and psl[i] == est == 0
