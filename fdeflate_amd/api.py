@@ -34,6 +34,8 @@ FLAG_FIRST_ONLY = 64
 FLAG_NO_SEGMENTS = 128
 FLAG_SPANS = 256
 FLAG_NO_FAST_GENERAL = 512
+FLAG_NO_INTERVALS = 0x400   # tests / A-B: skip the interval kernel (inflate_seg2.h)
+FLAG_INTERVALS_ONLY = 0x800  # debug: run only the interval kernel (what it leaves stays PENDING)
 
 
 class DecompressionError(Exception):

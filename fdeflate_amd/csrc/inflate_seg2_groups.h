@@ -132,7 +132,10 @@ __device__ __forceinline__ uint32_t seg2_count_group(uint32_t pairs, uint32_t rb
 // On return the accumulator has been stored; returns the last entry looked up.
 __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& lo, uint32_t& hi, uint32_t& c, uint32_t& ra,
                                                      uint32_t& acc) {
-    uint32_t e, t, u, nw, wa, sa, sb;
+    // The store of a step is issued BEHIND the table read of the next step (the LDS works in order:
+    // an atomic in front of the read would delay what the whole chain waits for), and the wait is for
+    // "all but the newest LDS operation".  x: the accumulator as it is stored; acc: as it goes on.
+    uint32_t e, t, u, nw, wa, sa, sb, x = acc;
     const uint32_t k4 = 4u;
     asm volatile(
         "  s_waitcnt lgkmcnt(0)\n"
@@ -141,19 +144,21 @@ __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& l
         "  v_mov_b32 " S2_VHI ", 0\n"
         "  v_lshrrev_b32 %[u], 3, %[c]\n"
         "  v_and_b32 %[sa], 24, %[u]\n"
+        "  v_lshrrev_b32 %[u], 6, %[c]\n"
+        "  v_and_b32 %[wa], -4, %[u]\n"
         "  ds_read_b32 %[nw], %[ra]\n"
         "Lpair_%=:\n"
         // step A: accumulator shift sa -> sb
         "  v_lshrrev_b64 " S2_SHF ", %[c], " S2_WIN "\n"
         "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
         "  ds_read_b32 %[e], %[t]\n"
+        "  ds_or_b32 %[wa], %[x]\n"  // the step before (at the start: the accumulator as it came in)
         "  v_lshrrev_b32 %[u], 6, %[c]\n"
         "  v_and_b32 %[wa], -4, %[u]\n"
-        "  s_waitcnt lgkmcnt(0)\n"
+        "  s_waitcnt lgkmcnt(1)\n"
         "  v_lshrrev_b32 " S2_VLO ", 8, %[e]\n"
         "  v_lshlrev_b64 " S2_T64 ", %[sa], " S2_V64 "\n"
-        "  v_or_b32 %[acc], %[acc], " S2_TLO "\n"
-        "  ds_or_b32 %[wa], %[acc]\n"
+        "  v_or_b32 %[x], %[acc], " S2_TLO "\n"
         S2_ADD_BYTE0("%[c]", "%[e]")
         "  v_lshrrev_b32 %[u], 3, %[c]\n"
         "  v_and_b32 %[sb], 24, %[u]\n"
@@ -161,15 +166,15 @@ __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& l
         // step B: sb -> sa
         "  v_lshrrev_b64 " S2_SHF ", %[c], " S2_WIN "\n"
         "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
-        "  v_cndmask_b32 %[acc], %[acc], " S2_THI ", vcc\n"
+        "  v_cndmask_b32 %[acc], %[x], " S2_THI ", vcc\n"
         "  ds_read_b32 %[e], %[t]\n"
+        "  ds_or_b32 %[wa], %[x]\n"
         "  v_lshrrev_b32 %[u], 6, %[c]\n"
         "  v_and_b32 %[wa], -4, %[u]\n"
-        "  s_waitcnt lgkmcnt(0)\n"
+        "  s_waitcnt lgkmcnt(1)\n"
         "  v_lshrrev_b32 " S2_VLO ", 8, %[e]\n"
         "  v_lshlrev_b64 " S2_T64 ", %[sb], " S2_V64 "\n"
-        "  v_or_b32 %[acc], %[acc], " S2_TLO "\n"
-        "  ds_or_b32 %[wa], %[acc]\n"
+        "  v_or_b32 %[x], %[acc], " S2_TLO "\n"
         S2_ADD_BYTE0("%[c]", "%[e]")
         "  v_lshrrev_b32 %[u], 3, %[c]\n"
         "  v_and_b32 %[sa], 24, %[u]\n"
@@ -177,7 +182,7 @@ __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& l
         // top the window up
         "  v_and_b32 %[t], 32, %[c]\n"
         "  v_and_b32 %[c], 0xffffffdf, %[c]\n"
-        "  v_cndmask_b32 %[acc], %[acc], " S2_THI ", vcc\n"
+        "  v_cndmask_b32 %[acc], %[x], " S2_THI ", vcc\n"
         "  v_cmp_ne_u32 vcc, 0, %[t]\n"
         "  s_sub_u32 %[pairs], %[pairs], 1\n"
         "  s_cmp_lg_u32 %[pairs], 0\n"
@@ -187,15 +192,16 @@ __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& l
         "  v_add_u32 %[ra], %[ra], %[t]\n"
         "  ds_read_b32 %[nw], %[ra]\n"
         "  s_cbranch_scc1 Lpair_%=\n"
-        // the bytes the last step left in the accumulator
+        // the last step's store, and the bytes it left in the accumulator
+        "  ds_or_b32 %[wa], %[x]\n"
         "  v_lshrrev_b32 %[u], 6, %[c]\n"
         "  v_and_b32 %[wa], -4, %[u]\n"
         "  ds_or_b32 %[wa], %[acc]\n"
         "  s_waitcnt lgkmcnt(0)\n"
         "  v_mov_b32 %[lo], " S2_WLO "\n"
         "  v_mov_b32 %[hi], " S2_WHI "\n"
-        : [pairs] "+s"(pairs), [lo] "+v"(lo), [hi] "+v"(hi), [c] "+v"(c), [ra] "+v"(ra), [acc] "+v"(acc), [e] "=&v"(e),
-          [t] "=&v"(t), [u] "=&v"(u), [nw] "=&v"(nw), [wa] "=&v"(wa), [sa] "=&v"(sa), [sb] "=&v"(sb)
+        : [pairs] "+s"(pairs), [lo] "+v"(lo), [hi] "+v"(hi), [c] "+v"(c), [ra] "+v"(ra), [acc] "+v"(acc), [x] "+v"(x),
+          [e] "=&v"(e), [t] "=&v"(t), [u] "=&v"(u), [nw] "=&v"(nw), [wa] "=&v"(wa), [sa] "=&v"(sa), [sb] "=&v"(sb)
         : [k4] "v"(k4)
         : "vcc", "scc", "memory", S2_CLOBBER8);
     return e;

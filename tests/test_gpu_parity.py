@@ -139,7 +139,8 @@ def test_valid_streams_every_decoder_variant(harness):
             names.append("%s@%d" % (name, c))
             blobs.append(comp)
             caps.append(c)
-    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8, 256, 256 | 8, 256 | 4 | 8):  # 256: span decoder (experimental)
+    # 256: span decoder (experimental); 0x400: without the interval kernel
+    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8, 256, 256 | 8, 256 | 4 | 8, 0x400, 0x400 | 8):
         harness.assert_inflate_parity(names, blobs, caps, flags=flags)
 
 
@@ -187,7 +188,10 @@ def test_segment_kernel_long_canonical_streams(harness):
         blobs.append(comp[:len(comp) * 2 // 3])
         caps.append(len(raw))
     harness.assert_inflate_parity(names, blobs, caps)
-    harness.assert_inflate_parity(names, blobs, caps, flags=128)
+    harness.assert_inflate_parity(names, blobs, caps, flags=0x400)        # without the interval kernel
+    harness.assert_inflate_parity(names, blobs, caps, flags=128)          # without both segment-parallel kernels
+    harness.assert_inflate_parity(names, blobs, caps, flags=1)            # ignore_adler32
+    harness.assert_inflate_parity(names, blobs, caps, flags=1 | 0x400)
 
 
 def test_segment_kernel_alone_short_and_unaligned(harness):
@@ -214,18 +218,20 @@ def test_segment_kernel_alone_short_and_unaligned(harness):
         names.append("s%d_trunc" % k)
         blobs.append(comp[:-3])
         caps.append(len(raw))
-    st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=64)
     rs, rl, ra, ro = harness.oracle_inflate(blobs, caps)
-    assert guards_ok, "the segment kernel wrote outside a slot"
-    taken = 0
-    for i, name in enumerate(names):
-        assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
-        if int(st[i]) == 0:
-            taken += 1
-            assert rs[i] == 0, (name, "reported Ok, reference says", ob.STATUS_NAMES[rs[i]])
-            assert int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
     plain = sum(1 for i in range(len(names)) if rs[i] == 0)
-    assert taken >= 0.9 * plain, (taken, plain)
+    # 0x800: the interval kernel alone; 0x400 | 64: the segment kernel alone; 64: both
+    for flags in (0x800, 0x400 | 64, 64):
+        st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=flags)
+        assert guards_ok, "a segment-parallel kernel wrote outside a slot (flags %#x)" % flags
+        taken = 0
+        for i, name in enumerate(names):
+            assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
+            if int(st[i]) == 0:
+                taken += 1
+                assert rs[i] == 0, (name, "reported Ok, reference says", ob.STATUS_NAMES[rs[i]])
+                assert int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
+        assert taken >= 0.9 * plain, (flags, taken, plain)
 
 
 def test_segment_kernel_random_stress(harness):
@@ -265,13 +271,15 @@ def test_segment_kernel_random_stress(harness):
         blobs.append(comp)
         caps.append(cap)
     harness.assert_inflate_parity(names, blobs, caps)
-    st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=64)
+    harness.assert_inflate_parity(names, blobs, caps, flags=0x400)
     rs, rl, ra, ro = harness.oracle_inflate(blobs, caps)
-    assert guards_ok
-    for i, name in enumerate(names):
-        assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
-        if int(st[i]) == 0:
-            assert rs[i] == 0 and int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
+    for flags in (0x800, 0x400 | 64):   # the interval kernel alone, the segment kernel alone
+        st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=flags)
+        assert guards_ok
+        for i, name in enumerate(names):
+            assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
+            if int(st[i]) == 0:
+                assert rs[i] == 0 and int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
 
 
 def test_valid_streams_ignore_adler(harness):
