@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the extra encode / zlib-6 lines")
     ap.add_argument("--general-streams", type=int, default=16384, help="streams given to the level-1 / RLE encoders (also lines)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline leg (4 legs)")
-    ap.add_argument("--zlib6-streams", type=int, default=16384)
+    ap.add_argument("--zlib6-streams", type=int, default=65536, help="SURVEY 8(d) C2 (ii): the same buffers as the headline")
+    ap.add_argument("--also-select", default="encode,level1,rle,png,zlib6",
+                    help="which extra lines to run (tools/profile.sh profiles them one by one)")
     ap.add_argument("--no-payload-gather", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: run the RCCL metadata gather even with one rank")
@@ -460,9 +462,13 @@ def main():
         if payload_ms is not None:
             res["payload_gather_ms"] = payload_ms
         also = []
+        sel = set(x for x in args.also_select.split(",") if x)
+        full = n == 65536
         if world == 1 and not args.no_also and args.mode == "decode" and args.format == "ultrafast":
             # BASELINE config 3: ultra-fast encode of the same buffers
             try:
+                if "encode" not in sel:
+                    raise KeyError("skipped")
                 enc_out = torch.empty(n * bound, dtype=torch.uint8, device=dev)
                 w2, k2 = time_steps(encode_step, args.steps, args.warmup, barrier)
                 elen = out_len.to(torch.int64)
@@ -474,12 +480,17 @@ def main():
                              "roofline": roofline(alg, k2avg, "deflate_ultrafast_kernel", profiled_traffic("encode")
                                                   if n == 65536 else None)})
                 del enc_out
+            except KeyError:
+                pass
             except Exception as e:
                 also.append({"workload": "BASELINE config 3 (encode)", "error": repr(e)})
             # the general encoder (level 1, RLE) on the same buffers
             for mode, label in ((fd.MODE_LEVEL1, "compress_to_vec (level 1, greedy parse + hash table)"),
                                 (fd.MODE_RLE, "compress_to_vec_rle (RLE parse)")):
                 try:
+                    key = "level1" if mode == fd.MODE_LEVEL1 else "rle"
+                    if key not in sel:
+                        continue
                     ng = min(n, args.general_streams)
                     gbound = (fd.compress_bound(L) + 15) & ~15
                     g_off = torch.arange(ng + 1, dtype=torch.int64, device=dev) * gbound
@@ -497,10 +508,14 @@ def main():
                         fd.deflate_general_batch(g_in, gr_off, gout, g_off, mode, glen)
                     barrier()
                     gw = time.perf_counter() - t0
+                    galg = ng * L + int(glen.to(torch.int64).sum()) + 24 * ng
                     entry = {"workload": "SURVEY 8f: %s of %d x %d KiB buffers" % (label, ng, L // 1024),
                              "metric": "input GB/s", "value": round(ng * L / (gw / gsteps) / 1e9, 3),
                              "ms_per_step": round(gw * 1e3 / gsteps, 4), "steps": gsteps,
-                             "ratio": round(float(glen.to(torch.int64).sum()) / (ng * L), 4)}
+                             "ratio": round(float(glen.to(torch.int64).sum()) / (ng * L), 4),
+                             # (host clock around a call that returns when the kernels are done)
+                             "roofline": roofline(galg, gw * 1e3 / gsteps, "deflate_parse_kernel + deflate_write_kernel",
+                                                  profiled_traffic(key) if ng == args.general_streams == 16384 else None)}
                     if want_cpu:
                         v, how = cpu_general_encode(native_so, raw[:64].cpu().numpy(), mode == fd.MODE_RLE, 1.5)
                         entry["cpu_port_1_thread"] = {"value": round(v, 4), "unit": "GB/s", "kind": "port",
@@ -512,6 +527,8 @@ def main():
             # decode + PNG scanline reconstruction in one call (the buffers are
             # 64 scanlines of 1023 bytes behind a filter-type byte each, RGB8)
             try:
+                if "png" not in sel:
+                    raise KeyError("skipped")
                 from fdeflate_amd import synth as _synth
                 rb_png, bpp_png = _synth.ROW_BYTES - 1, 3
                 rows_png = L // _synth.ROW_BYTES
@@ -534,16 +551,24 @@ def main():
                 assert int(fst.abs().sum()) == 0 and torch.equal(back, out), "filter(reconstruct(x)) != x"
                 del back, types
                 psteps = max(3, args.steps // 4)
-                w4, _k4 = time_steps(png_step, psteps, 1, barrier)
+                w4, k4 = time_steps(png_step, psteps, 1, barrier)
+                # algorithmic bytes: the decode's + the reconstruction's (scanlines read once, pixels written once)
+                palg = alg + n * L + n * rows_png * rb_png
                 also.append({"workload": "SURVEY 8f: inflate + PNG scanline reconstruction (fdh_inflate_png_batch) of the same "
                                          "%d streams, %d rows x %d bytes, %d bytes per pixel" % (n, rows_png, rb_png, bpp_png),
                              "metric": "decompressed GB/s", "value": round(n * L / (w4 / psteps) / 1e9, 3),
-                             "ms_per_step": round(w4 * 1e3 / psteps, 4), "steps": psteps})
+                             "ms_per_step": round(w4 * 1e3 / psteps, 4), "steps": psteps,
+                             "roofline": roofline(palg, sum(k4) / len(k4), "inflate_seg2_kernel + png_pipe_kernel",
+                                                  profiled_traffic("png") if full else None)})
                 del pix
+            except KeyError:
+                pass
             except Exception as e:
                 also.append({"workload": "SURVEY 8f: inflate + PNG reconstruction", "error": repr(e)})
             # BASELINE config 2 (ii): the same data as zlib level-6 streams (general kernels)
             try:
+                if "zlib6" not in sel:
+                    raise KeyError("skipped")
                 nz = min(n, args.zlib6_streams)
                 zcomp, zoff, zlen = encode_zlib6(raw[:nz].cpu().numpy(), dev)
                 zr_off = r_off[:nz + 1]
@@ -564,7 +589,10 @@ def main():
                              "metric": "decompressed GB/s", "value": round(nz * L / (w3 / zsteps) / 1e9, 3),
                              "ms_per_step": round(w3 * 1e3 / zsteps, 4), "steps": zsteps,
                              "roofline": roofline(zalg, sum(k3) / len(k3),
-                                                  "inflate_general_fast_kernel (+ inflate_general_kernel)", None)})
+                                                  "inflate_general_fast_kernel (+ inflate_general_kernel)",
+                                                  profiled_traffic("zlib6") if nz == 65536 else None)})
+            except KeyError:
+                pass
             except Exception as e:
                 also.append({"workload": "BASELINE config 2 (ii) (zlib-6 decode)", "error": repr(e)})
         if also:
