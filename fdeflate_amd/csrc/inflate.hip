@@ -47,6 +47,7 @@ struct CanonTables {
     // nl[32..64): the symbols in (length, symbol) order: length base | extra bits << 9 | 1 << 12 for a
     // length symbol, 1 << 13 for end-of-block (256, and 286 / 287: reference src/tables.rs:100)
     uint32_t nl[64];
+    uint32_t lit2[kLitSize];  // the interval kernel's table (seg2_entry_build), built once per device
     uint32_t status;   // build status (ST_OK expected)
 };
 __device__ CanonTables g_canon;
@@ -353,7 +354,11 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
     __shared__ Seg2Lds lds;
     // the hand-scheduled loops address the table from LDS offset 0 (`raw & 0x3ffc` IS the address)
     if (lds_offset(lds.lit) != 0) __builtin_trap();
-    for (int i = threadIdx.x; i < kLitSize; i += kS2Waves * kWave) lds.lit[i] = seg2_entry_build(a.canon_lit, (uint32_t)i);
+    {   // the table in this kernel's entry layout, built once per device by canon_build_kernel: a plain copy
+        const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit2);
+        uint4* dst = reinterpret_cast<uint4*>(lds.lit);
+        for (int i = threadIdx.x; i < kLitSize / 4; i += kS2Waves * kWave) dst[i] = src[i];
+    }
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     uint2* const ckpt = a.ckpt + (size_t)(blockIdx.x * kS2Waves + threadIdx.x / kWave) * kS2CkptPerWave;
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(kWave) void canon_build_kernel() {
     if (rc == RC_OK) rc = inf.parse_block_header();
     wave_sync();
     for (int i = lane; i < kLitSize; i += kWave) g_canon.lit[i] = lds.tables.lit[i];
+    for (int i = lane; i < kLitSize; i += kWave) g_canon.lit2[i] = seg2_entry_build(lds.tables.lit, (uint32_t)i);
     for (int i = lane; i < kDistSize; i += kWave) g_canon.dist[i] = lds.tables.dist[i];
     if (lane < 14) {
         uint32_t w = (uint32_t)g_canon_header[4 * lane] | ((uint32_t)g_canon_header[4 * lane + 1] << 8) |
@@ -618,7 +624,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             if (e != hipSuccess) return (int)e;
         }
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->len4, canon->hdr,
-                        fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr, canon->nl};
+                        fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr, canon->nl, canon->lit2};
         if (list && seg2) {  // interval kernel first; what it leaves goes through the segment kernel
             sa.ckpt = reinterpret_cast<uint2*>(list + list_words);
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);

@@ -145,6 +145,7 @@ struct SegArgs {
     const uint32_t* src_list;  // nullable: work on these streams only ([0] = count, [4..] = ids)
     uint2* ckpt;     // interval decoder (inflate_seg2.h): checkpoint scratch, kS2CkptPerWave entries per wavefront
     const uint32_t* canon_nl;  // ... and the canonical bookkeeping of the symbols >= 256 (CanonTables::nl)
+    const uint32_t* canon_lit2;  // ... and its decode table (CanonTables::lit2)
 };
 
 // Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).
