@@ -471,19 +471,9 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
 #pragma unroll
                 for (int q = 0; q < kSlot; q++) lds.lin[lane][par][q] = pf[q];
             }
-            {   // fetch the line of the slot entered in (step + 8, step + 16]
-                const int32_t d2 = ph ? 2 * kSlot - ph : 2 * kSlot;
-                int32_t c2 = c + d2;
-                const bool wrap = c2 >= (int32_t)P;
-                if (wrap) c2 -= (int32_t)P;
-                const PngPipeRow& d = wrap ? next : cur;
-                if ((uint32_t)c2 < N) {
-                    fetch(d, (uint32_t)c2 / kSlot, pf);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < kSlot; q++) pf[q] = make_uint4(0, 0, 0, 0);
-                }
-            }
+            // (the stores go out BEFORE the next line is requested: loads and stores share one in-order
+            // counter, and the wait in front of the parking above is for everything issued -- with the
+            // stores behind the loads it waited for the stores' round trip as well)
             {   // write out the line of the slot that ended in (step - 8, step]
                 int32_t cfs = c - ph - kSlot;
                 const bool back = cfs < 0;  // (that slot belongs to the row before)
@@ -502,6 +492,19 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
                         const uint64_t o16 = (uint64_t)(cf + q) * 16;
                         if (cf + q < N && o16 < rb) png_store_part(d.out + o16, lds.lout[lane][par][q], (uint32_t)min((uint64_t)16, rb - o16));
                     }
+                }
+            }
+            {   // fetch the line of the slot entered in (step + 8, step + 16]
+                const int32_t d2 = ph ? 2 * kSlot - ph : 2 * kSlot;
+                int32_t c2 = c + d2;
+                const bool wrap = c2 >= (int32_t)P;
+                if (wrap) c2 -= (int32_t)P;
+                const PngPipeRow& d = wrap ? next : cur;
+                if ((uint32_t)c2 < N) {
+                    fetch(d, (uint32_t)c2 / kSlot, pf);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < kSlot; q++) pf[q] = make_uint4(0, 0, 0, 0);
                 }
             }
         }
