@@ -10,7 +10,7 @@ from .api import (Decompressor, DecompressionError, OutputTooLarge, STATUS_NAMES
                   inflate_batch, ultrafast_bound, compress_to_vec_stored, deflate_stored_batch,
                   stored_size, compress_to_vec, compress_to_vec_rle, compress_bound, deflate_general_batch,
                   MODE_LEVEL1, MODE_RLE, inflate_batch_multi, init_devices, shutdown_devices, multi_uses_rccl,
-                  png_unfilter_batch, png_filter_batch, inflate_png_batch)
+                  png_unfilter_batch, png_filter_batch, inflate_png_batch, png_filter_deflate_ultrafast_batch)
 
 __all__ = [
     "Decompressor", "DecompressionError", "OutputTooLarge", "STATUS_NAMES", "FLAG_IGNORE_ADLER32",
@@ -18,5 +18,5 @@ __all__ = [
     "decompress_to_vec_bounded", "deflate_ultrafast_batch", "inflate_batch", "ultrafast_bound",
     "compress_to_vec_stored", "deflate_stored_batch", "stored_size", "compress_to_vec", "compress_to_vec_rle",
     "compress_bound", "deflate_general_batch", "MODE_LEVEL1", "MODE_RLE", "inflate_batch_multi", "init_devices",
-    "shutdown_devices", "multi_uses_rccl", "png_unfilter_batch", "png_filter_batch", "inflate_png_batch",
+    "shutdown_devices", "multi_uses_rccl", "png_unfilter_batch", "png_filter_batch", "inflate_png_batch", "png_filter_deflate_ultrafast_batch",
 ]

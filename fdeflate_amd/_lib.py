@@ -62,6 +62,8 @@ def lib():
     L.fdh_png_filter_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, u32, u32, vp]
     L.fdh_inflate_png_batch.restype = C.c_int
     L.fdh_inflate_png_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u32, u32, u32, vp]
+    L.fdh_png_filter_deflate_ultrafast_batch.restype = C.c_int
+    L.fdh_png_filter_deflate_ultrafast_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u64, u32, u32, vp]
     L.fdh_init.restype = C.c_int
     L.fdh_init.argtypes = [u64]
     L.fdh_shutdown.restype = C.c_int
@@ -99,7 +101,7 @@ EXPORTED_SYMBOLS = [
     "fdh_decompressor_new", "fdh_decompressor_free", "fdh_decompressor_ignore_adler32",
     "fdh_decompressor_is_done", "fdh_decompressor_read",
     "fdh_compress_bound", "fdh_deflate_general_batch", "fdh_compress_to_vec", "fdh_compress_to_vec_rle",
-    "fdh_png_unfilter_batch", "fdh_png_filter_batch", "fdh_inflate_png_batch",
+    "fdh_png_unfilter_batch", "fdh_png_filter_batch", "fdh_inflate_png_batch", "fdh_png_filter_deflate_ultrafast_batch",
     "fdh_init", "fdh_shutdown", "fdh_multi_device_count", "fdh_multi_uses_rccl", "fdh_inflate_batch_multi",
 ]
 

@@ -314,6 +314,20 @@ def png_filter_batch(pix, pix_off, types, types_off, filt, filt_off, row_bytes, 
     return png_status
 
 
+def png_filter_deflate_ultrafast_batch(pix, pix_off, types, types_off, out, out_off, row_bytes, bpp):
+    """Filter n images with the given per-row types and ultra-fast-encode the filtered bytes in one
+    kernel, no intermediate buffer (fdh_png_filter_deflate_ultrafast_batch) -> (out_len, png_status)."""
+    import torch
+    n = pix_off.numel() - 1
+    out_len = torch.empty(n, dtype=torch.int32, device=pix.device)
+    png_status = torch.empty(n, dtype=torch.int32, device=pix.device)
+    with _OnDevice(pix, pix_off, types, types_off, out, out_off, out_len, png_status) as stream:
+        _lib.check(_lib.lib().fdh_png_filter_deflate_ultrafast_batch(
+            _ptr(pix), _ptr(pix_off), _ptr(types), _ptr(types_off), _ptr(out), _ptr(out_off), _ptr(out_len),
+            _ptr(png_status), n, row_bytes, bpp, C.c_void_p(stream)))
+    return out_len, png_status
+
+
 def inflate_png_batch(comp, in_off, filt, filt_off, pix, pix_off, row_bytes, bpp, flags=0):
     """Decode n IDAT-style zlib streams and reconstruct their scanlines in one call
     (fdh_inflate_png_batch) -> (out_len, status, adler, png_status)."""

@@ -127,9 +127,131 @@ struct DeflateBatchArgs {
     const uint64_t* out_off;
     uint32_t* out_len;
     uint64_t n;
+    // PNG source (fdh_png_filter_deflate_ultrafast_batch): `in` holds pixel rows, the encoder's input
+    // is the filtered image -- a type byte + row_bytes filtered bytes per row -- computed on the fly
+    const uint8_t* types;       // one filter type per row
+    const uint64_t* types_off;
+    uint32_t* png_status;       // 0 ok, 1 a filter type > 4, 2 sizes do not fit
+    uint32_t row_bytes, bpp;
 };
 
-__global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(DeflateBatchArgs a) {
+// ---- PNG filtering as the encoder's source (PNG specification 9.2: filtering uses the RAW neighbours,
+// so every byte is independent of every other filtered byte) ----
+struct PngSource {
+    const uint8_t* pix;    // rows x rb pixel bytes
+    const uint8_t* types;  // rows filter types
+    uint32_t rb, bpp, rows;
+    __device__ __forceinline__ uint32_t predict(uint32_t t, uint32_t a, uint32_t b, uint32_t c) const {
+        const int p = (int)a + (int)b - (int)c;
+        const int pa = abs(p - (int)a), pb = abs(p - (int)b), pc = abs(p - (int)c);
+        const uint32_t paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+        return t == 1 ? a : (t == 2 ? b : (t == 3 ? (a + b) >> 1 : (t == 4 ? paeth : 0u)));
+    }
+    // byte `col` (0 = the type byte) of filtered row `row`
+    __device__ __forceinline__ uint32_t byte_at(uint32_t row, uint32_t col) const {
+        const uint32_t t = types[row];
+        if (col == 0) return t;
+        const uint32_t k = col - 1;
+        const uint8_t* cur = pix + (uint64_t)row * rb;
+        const uint32_t raw = cur[k];
+        const uint32_t a = k >= bpp ? cur[k - bpp] : 0u;
+        const uint32_t b = row ? cur[(int64_t)k - (int64_t)rb] : 0u;
+        const uint32_t c = (row && k >= bpp) ? cur[(int64_t)k - (int64_t)rb - (int64_t)bpp] : 0u;
+        return (raw - predict(t, a, b, c)) & 0xFFu;
+    }
+    // 8 filtered bytes from filtered offset `off` on (all inside the image), in two steps so that the
+    // loads of a chunk are all unconditional and one tile ahead of their use (a load inside a branch
+    // makes the compiler wait for EVERYTHING in flight at the join):
+    //   request  the usual case -- eight data bytes of one row with all their neighbours -- takes four
+    //            8-byte loads and the row's type; a chunk at a row's start or in the first row reads a
+    //            harmless in-bounds address instead and is redone byte by byte in `finish`
+    //   finish   byte-wise arithmetic on all eight bytes at once (the type is the same for the chunk)
+    struct Req {
+        uint64_t rw, lw, uw, cw;
+        uint32_t t, off;
+        bool fast;
+    };
+    __device__ __forceinline__ Req request(uint64_t off) const {
+        Req q;
+        const uint32_t rb1 = rb + 1;
+        const uint32_t o32 = (uint32_t)off;  // (the filtered image is shorter than 2 GiB)
+        const uint32_t row = o32 / rb1, col = o32 - row * rb1;
+        q.off = o32;
+        q.fast = col >= 1 + bpp && col + 8 <= rb1 && row > 0;
+        const uint32_t trow = row < rows ? row : 0u;
+        q.t = types[trow];
+        // (not fast: any address at which 8 bytes and the three neighbours are readable -- the same
+        // place in the second row if there is one, else nothing is loaded)
+        const bool can = q.fast || (rows >= 2 && rb >= 8 + bpp);
+        const uint8_t* cur = q.fast ? pix + (uint64_t)row * rb + (col - 1) : pix + rb + bpp;
+        q.rw = q.lw = q.uw = q.cw = 0;
+        if (can) {
+            q.rw = *reinterpret_cast<const uint64_t*>(cur);  // (the hardware handles misalignment)
+            q.lw = *reinterpret_cast<const uint64_t*>(cur - bpp);
+            q.uw = *reinterpret_cast<const uint64_t*>(cur - rb);
+            q.cw = *reinterpret_cast<const uint64_t*>(cur - rb - bpp);
+        }
+        return q;
+    }
+    __device__ __forceinline__ uint64_t finish(const Req& q, bool wanted) const {
+        const uint64_t rw = q.rw, lw = q.lw, uw = q.uw, cw = q.cw;
+        const uint64_t H = 0x8080808080808080ull;
+        auto sub8 = [&](uint64_t p, uint64_t r) { return ((p | H) - (r & ~H)) ^ ((p ^ ~r) & H); };  // p - r per byte
+        uint64_t x = rw;
+        const uint32_t t = q.fast ? q.t : 0u;
+        if (t == 1) x = sub8(rw, lw);
+        if (t == 2) x = sub8(rw, uw);
+        if (t == 3) x = sub8(rw, (lw & uw) + (((lw ^ uw) >> 1) & 0x7F7F7F7F7F7F7F7Full));  // floor((a + b) / 2)
+        if (__any(t == 4)) {  // Paeth: byte by byte
+            uint64_t y = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t raw = (uint32_t)(rw >> (8 * j)) & 0xFF, a = (uint32_t)(lw >> (8 * j)) & 0xFF;
+                const uint32_t b = (uint32_t)(uw >> (8 * j)) & 0xFF, c = (uint32_t)(cw >> (8 * j)) & 0xFF;
+                const int p = (int)a + (int)b - (int)c;
+                const int pa = abs(p - (int)a), pb = abs(p - (int)b), pc = abs(p - (int)c);
+                const uint32_t pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                y |= (uint64_t)((raw - pr) & 0xFFu) << (8 * j);
+            }
+            x = t == 4 ? y : x;
+        }
+        if (__any(wanted && !q.fast)) {  // a row's first chunk, the first row: byte by byte (loads: see above)
+            if (wanted && !q.fast) {
+                // all the bytes are requested before the first one is used: one trip to memory, not eight
+                const uint32_t rb1 = rb + 1;
+                uint32_t r = q.off / rb1, cc = q.off - r * rb1;
+                uint32_t tt[8], raw[8], pa[8], pb[8], pc[8];
+                bool isdata[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t k = cc ? cc - 1 : 0u;
+                    const uint8_t* cur = pix + (uint64_t)r * rb;
+                    isdata[j] = cc != 0;
+                    tt[j] = types[r];
+                    const bool l_ok = isdata[j] && k >= bpp, u_ok = isdata[j] && r != 0;
+                    raw[j] = isdata[j] ? cur[k] : 0u;
+                    pa[j] = l_ok ? cur[k - bpp] : 0u;
+                    pb[j] = u_ok ? cur[(int64_t)k - (int64_t)rb] : 0u;
+                    pc[j] = (l_ok && u_ok) ? cur[(int64_t)k - (int64_t)rb - (int64_t)bpp] : 0u;
+                    if (++cc == rb1) {
+                        cc = 0;
+                        r++;
+                    }
+                }
+                x = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t v = isdata[j] ? (raw[j] - predict(tt[j], pa[j], pb[j], pc[j])) & 0xFFu : tt[j];
+                    x |= (uint64_t)v << (8 * j);
+                }
+            }
+        }
+        return x;
+    }
+};
+
+template <bool PNG>
+__global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
     __shared__ EncLds lds;
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x / kWave;
@@ -140,7 +262,27 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
     if (sid >= a.n) return;
 
     const uint8_t* in = a.in + a.in_off[sid];
-    const uint64_t len = a.in_off[sid + 1] - a.in_off[sid];
+    uint64_t len = a.in_off[sid + 1] - a.in_off[sid];
+    PngSource png{nullptr, nullptr, 0, 0, 0};
+    if (PNG) {  // the encoder's input: rows x (1 + row_bytes) filtered bytes
+        const uint64_t plen = len, nrows = plen / a.row_bytes;
+        const uint64_t tlen = a.types_off[sid + 1] - a.types_off[sid];
+        uint32_t st = (nrows * a.row_bytes != plen || tlen != nrows || nrows >= (1ull << 31) / (a.row_bytes + 1ull)) ? 2u : 0u;
+        png.pix = in;
+        png.types = a.types + a.types_off[sid];
+        png.rb = a.row_bytes;
+        png.bpp = a.bpp;
+        png.rows = st ? 0u : (uint32_t)nrows;
+        bool bad_type = false;
+        for (uint32_t r = (uint32_t)lane; r < png.rows; r += kWave) bad_type = bad_type || png.types[r] > 4;
+        if (__any(bad_type)) st = 1;
+        if (lane == 0) a.png_status[sid] = st;
+        if (st) {
+            if (lane == 0) a.out_len[sid] = 0;
+            return;
+        }
+        len = nrows * (a.row_bytes + 1ull);
+    }
     uint8_t* out = a.out + a.out_off[sid];
     const uint64_t cap = a.out_off[sid + 1] - a.out_off[sid];
 
@@ -178,13 +320,24 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
     // put a full trip to memory into every tile.
     const uint64_t last_chunk = nchunks ? nchunks - 1 : 0;
     uint64_t x_next = 0;
-    if (nchunks) x_next = *reinterpret_cast<const uint64_t*>(in + min((uint64_t)lane, last_chunk) * 8);  // HW handles misalignment
+    PngSource::Req req{0, 0, 0, 0, 0, 0, true};  // PNG: the chunk of the tile after next, requested
+    if (PNG) {
+        if (nchunks) x_next = png.finish(png.request(min((uint64_t)lane, last_chunk) * 8), (uint64_t)lane < nchunks);
+        if (nchunks) req = png.request(min((uint64_t)lane + kWave, last_chunk) * 8);
+    } else if (nchunks) {
+        x_next = *reinterpret_cast<const uint64_t*>(in + min((uint64_t)lane, last_chunk) * 8);  // HW handles misalignment
+    }
     if ((uint64_t)lane >= nchunks) x_next = 0;
     for (uint64_t t0 = 0; t0 < nchunks; t0 += kWave) {
         const uint64_t c = t0 + lane;
         const bool valid = c < nchunks;
         const uint64_t x = x_next;
-        x_next = *reinterpret_cast<const uint64_t*>(in + min(c + kWave, last_chunk) * 8);
+        if (PNG) {
+            x_next = png.finish(req, c + kWave < nchunks);             // tile t + 1: requested a tile ago
+            req = png.request(min(c + 2 * kWave, last_chunk) * 8);     // tile t + 2
+        } else {
+            x_next = *reinterpret_cast<const uint64_t*>(in + min(c + kWave, last_chunk) * 8);
+        }
         if (c + kWave >= nchunks) x_next = 0;
         const uint32_t nvalid = (uint32_t)min((uint64_t)kWave, nchunks - t0);
         {   // adler partials: weight of byte j of this chunk is len - (c*8 + j)
@@ -291,7 +444,8 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
         const uint32_t rem = (uint32_t)(len & 7);
         uint32_t bits = 0, nb = 0;
         if ((uint32_t)lane < rem) {
-            uint32_t bv = in[nchunks * 8 + lane];
+            const uint64_t ro = nchunks * 8 + lane;
+            uint32_t bv = PNG ? png.byte_at((uint32_t)ro / (png.rb + 1), (uint32_t)ro % (png.rb + 1)) : in[ro];
             uint32_t e = lds.tab[bv];
             bits = e & 0xFFFF;
             nb = e >> 16;
@@ -329,9 +483,22 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel(De
 extern "C" int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
                                             const uint64_t* out_off, uint32_t* out_len, uint64_t n,
                                             hipStream_t stream) {
-    fdh::DeflateBatchArgs a{in, in_off, out, out_off, out_len, n};
+    fdh::DeflateBatchArgs a{in, in_off, out, out_off, out_len, n, nullptr, nullptr, nullptr, 0, 0};
     if (n == 0) return 0;
     unsigned blocks = (unsigned)((n + fdh::kEncWaves - 1) / fdh::kEncWaves);
-    hipLaunchKernelGGL(fdh::deflate_ultrafast_kernel, dim3(blocks), dim3(fdh::kEncWaves * fdh::kWave), 0, stream, a);
+    hipLaunchKernelGGL(fdh::deflate_ultrafast_kernel_t<false>, dim3(blocks), dim3(fdh::kEncWaves * fdh::kWave), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+// PNG filtering fused into the encoder: pixel rows in, zlib stream of the filtered image out; the
+// filtered bytes exist only in registers.
+extern "C" int fdh_launch_png_filter_deflate_ultrafast(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types,
+                                                       const uint64_t* types_off, uint8_t* out, const uint64_t* out_off,
+                                                       uint32_t* out_len, uint32_t* png_status, uint64_t n,
+                                                       uint32_t row_bytes, uint32_t bpp, hipStream_t stream) {
+    fdh::DeflateBatchArgs a{pix, pix_off, out, out_off, out_len, n, types, types_off, png_status, row_bytes, bpp};
+    if (n == 0) return 0;
+    unsigned blocks = (unsigned)((n + fdh::kEncWaves - 1) / fdh::kEncWaves);
+    hipLaunchKernelGGL(fdh::deflate_ultrafast_kernel_t<true>, dim3(blocks), dim3(fdh::kEncWaves * fdh::kWave), 0, stream, a);
     return (int)hipGetLastError();
 }

@@ -21,6 +21,10 @@ int fdh_launch_build_tables_debug(const uint8_t* code_lengths, uint32_t hlit, ui
                                   uint32_t* build_status, hipStream_t stream);
 int fdh_launch_deflate_stored(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                               uint32_t* out_len, uint64_t n, hipStream_t stream);
+int fdh_launch_png_filter_deflate_ultrafast(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types,
+                                            const uint64_t* types_off, uint8_t* out, const uint64_t* out_off,
+                                            uint32_t* out_len, uint32_t* png_status, uint64_t n, uint32_t row_bytes,
+                                            uint32_t bpp, hipStream_t stream);
 int fdh_launch_deflate_ultrafast(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                                  uint32_t* out_len, uint64_t n, hipStream_t stream);
 int fdh_launch_deflate_general(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
@@ -204,6 +208,21 @@ int fdh_png_filter_batch(const uint8_t* pix, const uint64_t* pix_off, const uint
     rc = fdh_launch_png_filter(pix, pix_off, types, types_off, filt, filt_off, png_status, n, row_bytes, bpp,
                                static_cast<hipStream_t>(hip_stream));
     if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "filter kernel launch");
+    return FDH_SUCCESS;
+}
+
+int fdh_png_filter_deflate_ultrafast_batch(const uint8_t* pix, const uint64_t* pix_off, const uint8_t* types,
+                                           const uint64_t* types_off, uint8_t* out, const uint64_t* out_off,
+                                           uint32_t* out_len, uint32_t* png_status, uint64_t n, uint32_t row_bytes,
+                                           uint32_t bpp, void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    int rc = png_args_ok(pix, pix_off, out, out_off, png_status, row_bytes, bpp);
+    if (rc != FDH_SUCCESS) return rc;
+    if (!types || !types_off || !out_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null pointer");
+    if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many buffers in one call (max 2^31-1)");
+    rc = fdh_launch_png_filter_deflate_ultrafast(pix, pix_off, types, types_off, out, out_off, out_len, png_status, n,
+                                                 row_bytes, bpp, static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "filter + deflate kernel launch");
     return FDH_SUCCESS;
 }
 

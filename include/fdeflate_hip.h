@@ -173,6 +173,15 @@ int fdh_png_filter_batch(const uint8_t *pix, const uint64_t *pix_off, const uint
                          const uint64_t *types_off, uint8_t *filt, const uint64_t *filt_off,
                          uint32_t *png_status, uint64_t n, uint32_t row_bytes, uint32_t bpp,
                          void *hip_stream);
+/* Filtering fused into the ultra-fast encoder: pixel rows in (`pix`, rows_i x row_bytes), one filter
+ * type per row in `types`, out the zlib stream compress_to_vec_ultra_fast(filtered image) -- what an
+ * IDAT holds.  The filtered bytes exist only in registers (no intermediate buffer).  Slots of at
+ * least fdh_ultrafast_bound(rows_i * (row_bytes + 1)) bytes; out_len[i] = 0 where png_status[i] != 0. */
+int fdh_png_filter_deflate_ultrafast_batch(const uint8_t *pix, const uint64_t *pix_off,
+                                           const uint8_t *types, const uint64_t *types_off,
+                                           uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
+                                           uint32_t *png_status, uint64_t n, uint32_t row_bytes,
+                                           uint32_t bpp, void *hip_stream);
 int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *filt,
                           const uint64_t *filt_off, uint32_t *out_len, uint32_t *status,
                           uint32_t *adler, uint8_t *pix, const uint64_t *pix_off,

@@ -866,3 +866,57 @@ def test_png_filters_bit_exact_and_fused_decode(harness):
             os.environ.pop("FDH_PNG_IMAGES_PER_WAVE", None)
         else:
             os.environ["FDH_PNG_IMAGES_PER_WAVE"] = old3
+
+
+@pytest.mark.gpu
+def test_png_filter_fused_into_the_ultrafast_encoder():
+    """fdh_png_filter_deflate_ultrafast_batch: pixel rows in, the zlib stream of the filtered image
+    out, bit for bit what the oracle's filter followed by the oracle's ultra-fast encoder gives --
+    every pixel size, rows shorter than a chunk, rows that are no multiple of a chunk, every
+    filter type, images of one row, an empty image, a bad filter type and a size that does not fit."""
+    import torch
+    import fdeflate_amd as fd
+    r = np.random.default_rng(31)
+    cases = []   # (pix bytes, types, row_bytes, bpp)
+    for bpp in (1, 2, 3, 4, 6, 8):
+        for rb in (bpp, 2 * bpp, 7 * bpp, 1023 // bpp * bpp, 40 * bpp + bpp):
+            for rows in (1, 2, 5, 64):
+                pix = r.integers(0, 256, rows * rb, dtype=np.uint8)
+                pix[r.random(rows * rb) < 0.4] = 0
+                if rows >= 5:
+                    pix[rb:3 * rb] = 0       # zero rows: runs in the encoder
+                types = r.integers(0, 5, rows, dtype=np.uint8)
+                cases.append((pix.tobytes(), bytes(types), rb, bpp))
+    for (rb, bpp) in sorted(set((c[2], c[3]) for c in cases)):
+        group = [c for c in cases if c[2] == rb and c[3] == bpp]
+        group.append((b"", b"", rb, bpp))                                        # an empty image
+        group.append((bytes(rb * 3), bytes([0, 5, 1]), rb, bpp))                 # a bad filter type
+        group.append((bytes(rb * 3 + 1) if rb > 1 else bytes(3), bytes(3), rb, bpp))   # rows do not divide / fit
+        pbuf, poff = streams.pack_exact([c[0] for c in group])
+        tbuf, toff = streams.pack_exact([c[1] for c in group])
+        bound = [int(fd.ultrafast_bound((len(c[0]) // rb) * (rb + 1))) + 16 for c in group]
+        ooff = np.zeros(len(group) + 1, dtype=np.int64)
+        ooff[1:] = np.cumsum(bound)
+        d_out = torch.full((int(ooff[-1]),), 0xEE, dtype=torch.uint8, device="cuda")
+        ol, st = fd.png_filter_deflate_ultrafast_batch(
+            torch.from_numpy(pbuf).cuda(), torch.from_numpy(poff.astype(np.int64)).cuda(),
+            torch.from_numpy(tbuf).cuda() if tbuf.size else torch.zeros(1, dtype=torch.uint8, device="cuda"),
+            torch.from_numpy(toff.astype(np.int64)).cuda(), d_out, torch.from_numpy(ooff).cuda(), rb, bpp)
+        torch.cuda.synchronize()
+        h, oll, stl = d_out.cpu().numpy(), ol.cpu().tolist(), st.cpu().tolist()
+        for i, (pix, types, _, _) in enumerate(group):
+            if i == len(group) - 2:
+                assert stl[i] == 1 and oll[i] == 0, (rb, bpp, i)
+                continue
+            if i == len(group) - 1 and rb > 1:
+                assert stl[i] == 2 and oll[i] == 0, (rb, bpp, i)
+                continue
+            if i == len(group) - 1:
+                continue
+            est, filt = ob.png_filter(pix, rb, bpp, types)
+            assert est == 0 and stl[i] == 0, (rb, bpp, i, stl[i])
+            want = ob.compress_ultra_fast(filt)
+            got = h[ooff[i]:ooff[i] + oll[i]].tobytes()
+            assert got == want, (rb, bpp, i, len(got), len(want))
+            assert zlib.decompress(got) == filt
+            assert np.all(h[ooff[i] + oll[i]:ooff[i + 1]] == 0xEE)   # nothing behind the stream

@@ -22,3 +22,44 @@ for _ in range(3):
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 5)
 print("png reconstruction of %d images: %.3f ms (%.0f GB/s of filtered bytes)" % (n, best, n * L / best / 1e6))
+
+# filter -> ultra-fast encode: fused kernel against the two separate calls
+types = raw.view(n, rows, rb + 1)[:, :, 0].contiguous().view(-1) % 5
+t_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * rows
+pixels = pix   # (whatever the reconstruction left there: it is only a byte source)
+bound = (fd.ultrafast_bound(L) + 15) & ~15
+o_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * bound
+enc = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+filt = torch.empty(n * L, dtype=torch.uint8, device=dev)
+
+
+def fused():
+    return fd.png_filter_deflate_ultrafast_batch(pixels, p_off, types, t_off, enc, o_off, rb, bpp)
+
+
+def separate():
+    fd.png_filter_batch(pixels, p_off, types, t_off, filt, r_off, rb, bpp)
+    return fd.deflate_ultrafast_batch(filt, r_off, enc, o_off)
+
+
+def best_of(f):
+    f(); torch.cuda.synchronize()
+    b = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): f()
+        e1.record(); torch.cuda.synchronize()
+        b = min(b, e0.elapsed_time(e1) / 5)
+    return b
+
+
+ol_f, st_f = fused(); torch.cuda.synchronize()
+enc_f = enc.clone()
+ol_s = separate(); torch.cuda.synchronize()
+same = bool((ol_f == ol_s).all()) and int(st_f.abs().sum()) == 0
+# compare the streams themselves (the slots' tails are not defined)
+idx = torch.arange(bound, device=dev).unsqueeze(0) < ol_s.to(torch.int64).unsqueeze(1)
+same = same and bool(((enc_f.view(n, bound) == enc.view(n, bound)) | ~idx).all())
+tf, ts = best_of(fused), best_of(separate)
+print("filter + ultra-fast encode of %d images: fused %.3f ms, separate calls %.3f ms, same streams: %s" % (n, tf, ts, same))
