@@ -352,13 +352,16 @@ __device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes&
     S2PF(7);
     if (running) rd.refill_now();
     S2PF(0);
+    bool parked = false;  // the lane sits on a token that is no literal and waits for the general step
+    uint32_t iter = 0;
     while (__any(running)) {
         s2_event(rd, ck, running);
         S2PF(1);
         // one group per event: 16 look-ups for the lanes that have the input for it (what an event
         // guarantees), or, when no lane has, 8; a lane that cannot take part takes one token
-        const bool f2 = running && s.pos + 2 * kSegGroupBits <= limit && rd.level() >= kSegEventNeed;
-        const bool f1 = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
+        const bool can = running && !parked;
+        const bool f2 = can && s.pos + 2 * kSegGroupBits <= limit && rd.level() >= kSegEventNeed;
+        const bool f1 = can && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
         const uint32_t pairs = __any(f2) ? 2 * kS2Pairs : kS2Pairs;
         bool fast = pairs == kS2Pairs ? f1 : f2;
         bool general = running && !fast && rd.level() >= 2;
@@ -366,10 +369,20 @@ __device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes&
             s2_ck_meter(ck, s, fast, 2 * pairs);
             fast = fast && s.stop == 0;
             S2PF(2);
-            if (fast) general = s2_ring_group(pairs, rd, rb, s) == 0;
+            if (fast) {
+                parked = s2_ring_group(pairs, rd, rb, s) == 0;
+                general = parked;
+            }
             S2PF(3);
         }
-        if (__any(general)) s2_count_general<false>(lit, cd, rd, s, ck, general, false, stop_at, limit);
+        // The general step is the same work for one lane as for sixty-four: a few lanes that have met a
+        // run wait for every other iteration (they do nothing meanwhile) unless nobody is in a group.
+        const uint64_t gmask = __ballot(general);
+        if (gmask && ((iter & 1) != 0 || __popcll(gmask) >= 6 || !__any(fast))) {
+            s2_count_general<false>(lit, cd, rd, s, ck, general, false, stop_at, limit);
+            parked = false;
+        }
+        iter++;
         running = running && s.stop == 0 && s.pos < stop_at;
         S2PF(4);
     }
