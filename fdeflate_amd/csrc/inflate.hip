@@ -76,7 +76,8 @@ struct InflateBatchArgs {
     uint64_t n;
     uint32_t flags;
     uint32_t only_pending;
-    const uint32_t* list;  // nullable: compacted ids of the PENDING streams ([0] = count, [4..] = ids)
+    uint32_t* list;  // nullable: compacted ids of the PENDING streams ([0] = count, [2] / [3] = hand-out counters of
+                     // the fast / the 12-bit general kernel, [4..] = ids)
     uint32_t* span_pool;   // nullable: kSpanSlots busy flags, then kSpanSlots match lists (span decoder scratch)
 };
 constexpr uint32_t kSpanSlots = 2048;  // > workgroups of the general kernel resident on one device (256 CUs x 5)
@@ -158,11 +159,15 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
 }
 __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs a) {
     __shared__ GeneralLds lds;
-    if (a.list) {  // only the streams a kernel in front has listed as left over (a grid-stride loop over the list)
+    if (a.list) {  // only the streams a kernel in front has listed as left over, handed out by a counter
         const uint32_t cnt = a.list[0];
-        for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        // (the first item of a workgroup is its own index, the following ones come from a counter: an
+        // empty list costs no atomic -- four thousand of them on one address are 80 us)
+        for (uint32_t i = blockIdx.x; i < cnt;) {
             general_one(a, lds, a.list[4 + i]);
             wave_sync();
+            if (threadIdx.x == 0) i = atomicAdd(&a.list[3], 1u) + gridDim.x;
+            i = uni(i);
         }
         return;
     }
@@ -210,9 +215,11 @@ __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_genera
     __shared__ GeneralFastLds lds;
     if (a.list) {
         const uint32_t cnt = a.list[0];
-        for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        for (uint32_t i = blockIdx.x; i < cnt;) {
             general_fast_one(a, lds, a.list[4 + i]);
             wave_sync();
+            if (threadIdx.x == 0) i = atomicAdd(&a.list[2], 1u) + gridDim.x;
+            i = uni(i);
         }
         return;
     }
@@ -654,7 +661,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             e = hipGetLastError();
             // the general kernels walk the same list (what the canon kernel finished is no longer PENDING):
             // a grid-stride loop, so a batch that is all canonical costs two near-empty launches
-            const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 8192);
+            const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 4096);  // persistent workgroups (16 per CU at most)
             if (e == hipSuccess && !(flags & 0x200u)) {
                 hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3(gblocks), dim3(fdh::kWave), 0, stream, a);
                 e = hipGetLastError();
