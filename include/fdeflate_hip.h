@@ -208,7 +208,19 @@ int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *fi
  * and is sticky.  An EMPTY input asks for whatever can still be produced from the bytes already
  * handed over (how the reference's own test harness, src/decompress/tests/test_utils.rs:70-74, and
  * the png crate finish a stream).  Function return = infrastructure status as everywhere else.
- * `output_position > output_len` (a panic in the reference, :189) is FDH_ERR_INVALID_ARGUMENT. */
+ * `output_position > output_len` (a panic in the reference, :189) is FDH_ERR_INVALID_ARGUMENT.
+ *
+ * Where the (consumed, produced) pairs differ from the reference's -- the bytes delivered over a whole
+ * stream, their order, the final status and is_done never do (tests/test_gpu_streaming.py):
+ *   1. *consumed == input_len on EVERY call: the input is buffered on the device, whereas the reference
+ *      stops consuming once the output is full (src/decompress.rs:167-170).  A caller written against
+ *      the contract ("consumed bytes must not be offered again") behaves identically.
+ *   2. With more than 256 KiB of buffered input a call with NON-EMPTY input may return (input_len, 0)
+ *      without a decode attempt (attempts are then made when the stream has grown by 1/8, and on every
+ *      EMPTY input).  A caller must therefore conclude "truncated" (the reference's InsufficientInput,
+ *      src/decompress.rs:1135-1136) only after a read with empty input has produced nothing and
+ *      is_done is still false -- which is what the reference's own harness and the png crate do at
+ *      the end of their input anyway. */
 typedef struct fdh_decompressor fdh_decompressor;
 fdh_decompressor *fdh_decompressor_new(void);
 void fdh_decompressor_free(fdh_decompressor *d);

@@ -165,10 +165,13 @@ pub fn decompress_to_vec(input: &[u8]) -> Result<Vec<u8>, DecompressionError> {
     let (mut p, mut n, mut status) = (std::ptr::null_mut(), 0usize, 0u32);
     check(unsafe { ffi::fdh_decompress_to_vec(input.as_ptr(), input.len(), &mut p, &mut n, &mut status) });
     let v = unsafe { take(p, n) };
-    if status == 0 {
-        Ok(v)
-    } else {
-        Err(to_error(status))
+    match status {
+        0 => Ok(v),
+        // the C ABI decodes into slots of at most 4 GiB - 1 bytes: an output that does not fit is an
+        // infrastructure limit of this drop-in (the reference would go on growing the Vec), reported
+        // like an allocation failure there -- a panic with a message, not a bogus `DecompressionError`
+        ffi::FDH_OUTPUT_TOO_LARGE => panic!("fdeflate_hip: decompressed output exceeds the 4 GiB slot limit of the C ABI"),
+        s => Err(to_error(s)),
     }
 }
 
