@@ -247,8 +247,8 @@ int fdh_inflate_png_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* fi
 
 // ---- general encoder (level 1 / RLE): per-device workspace, grown on demand, never shrunk ----
 namespace {
-std::mutex g_gen_mutex;
 struct GenWork {
+    std::mutex mutex;         // the workspace is shared by the calls on ITS device only
     void* hash = nullptr;     // one 64 Ki-entry table per resident lane of the parser (level 1)
     void* matches = nullptr;  // what the parser hands to the block writer, sliced per stream
     void* blocks = nullptr;
@@ -257,13 +257,13 @@ struct GenWork {
 };
 GenWork g_gen_work[64];
 
-int grow(void** p, size_t* have, size_t want, const char* what) {
+int grow(void** p, size_t* have, size_t want, const char* what, bool headroom = true) {
     if (*have >= want) return FDH_SUCCESS;
     HIP_TRY(hipDeviceSynchronize());  // nobody may still be using the old buffer
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *have = 0;
-    const size_t sz = want + want / 4;  // some headroom: batches of similar size do not reallocate
+    const size_t sz = headroom ? want + want / 4 : want;  // headroom: batches of similar size do not reallocate
     hipError_t e = hipMalloc(p, sz);
     if (e != hipSuccess) {
         *p = nullptr;
@@ -280,6 +280,7 @@ int fdh_deflate_general_batch(const uint8_t* in, const uint64_t* in_off, uint8_t
                               uint32_t* out_len, uint64_t n, uint32_t mode, void* hip_stream) {
     if (n == 0) return FDH_SUCCESS;
     if (!in_off || !out_off || !out_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
+    if (!in || !out) return fail(FDH_ERR_INVALID_ARGUMENT, "null data pointer");
     if (mode != FDH_MODE_LEVEL1 && mode != FDH_MODE_RLE) return fail(FDH_ERR_INVALID_ARGUMENT, "unknown encoder mode");
     if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many streams in one call");
     if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
@@ -308,11 +309,20 @@ int fdh_deflate_general_batch(const uint8_t* in, const uint64_t* in_off, uint8_t
         if (v >= 1 && v <= 64) lanes = (unsigned)v;
     }
     const uint64_t max_resident = 32768;
-    const unsigned waves = (unsigned)std::min<uint64_t>((n + lanes - 1) / lanes, std::max<uint64_t>(1, max_resident / lanes));
-    std::lock_guard<std::mutex> lock(g_gen_mutex);  // the workspace is shared by the calls on this device
+    unsigned waves = (unsigned)std::min<uint64_t>((n + lanes - 1) / lanes, std::max<uint64_t>(1, max_resident / lanes));
     GenWork& w = g_gen_work[dev];
+    std::lock_guard<std::mutex> lock(w.mutex);
     int rc = FDH_SUCCESS;
-    if (!rle) rc = grow(&w.hash, &w.hash_bytes, (size_t)waves * lanes * fdh_deflate_general_hash_bytes(), "hipMalloc(hash tables)");
+    if (!rle) {
+        // exactly the resident lanes' tables (no headroom: at the cap that is the documented 8 GiB);
+        // on a smaller or busy device the batch runs with fewer resident wavefronts instead of failing
+        for (;;) {
+            rc = grow(&w.hash, &w.hash_bytes, (size_t)waves * lanes * fdh_deflate_general_hash_bytes(), "hipMalloc(hash tables)", false);
+            if (rc == FDH_SUCCESS || waves <= 1) break;
+            (void)hipGetLastError();
+            waves /= 2;
+        }
+    }
     if (rc == FDH_SUCCESS)
         rc = grow(&w.matches, &w.match_bytes, fdh_deflate_general_match_records(total_in, n) * fdh_deflate_general_match_record_bytes(),
                   "hipMalloc(back-reference records)");
