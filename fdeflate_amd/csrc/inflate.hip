@@ -502,8 +502,8 @@ extern "C" int fdh_debug_read_seg2(uint32_t* host) {
 }
 extern "C" int fdh_debug_read_gstat(unsigned long long* host, int reset) {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_gstat), 16 * 8);
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_gstat), z, 16 * 8); }
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_gstat), 24 * 8);
+    if (reset) { unsigned long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_gstat), z, 24 * 8); }
     return 0;
 }
 extern "C" int fdh_debug_read_segtime(uint32_t* host) {

@@ -110,6 +110,7 @@ static_assert(sizeof(Seg2Lds) == 160 * 1024, "one workgroup owns the LDS of its 
 // symbol, and the range of lengths to try (uniform).
 struct S2Codes {
     uint32_t parm, tab, lmin, lmax, len4;
+    bool edge;  // (uniform) the stream ends close to the end of the input buffer: careful loads, see s2_event
 };
 __device__ __forceinline__ S2Codes s2_codes(const SegArgs& a) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -119,6 +120,7 @@ __device__ __forceinline__ S2Codes s2_codes(const SegArgs& a) {
     c.lmin = uni(a.canon_nl[16]);
     c.lmax = uni(a.canon_nl[17]);
     c.len4 = a.canon_len4[lane & 31];
+    c.edge = true;
     return c;
 }
 
@@ -221,8 +223,12 @@ __device__ __forceinline__ void s2_ck_store(S2Ck& k, const S2Scan& s, bool doit)
 }
 // One input event of a counting scan: the pair of chunks requested an event ago goes into the ring
 // (this is where the wavefront waits for memory), THEN the checkpoints cut since are stored, THEN
-// the next pair is requested.
-__device__ __forceinline__ void s2_event(SegReader& rd, S2Ck& ck, bool want) {
+// the next pair is requested.  `edge` (uniform: the stream lies within a few hundred bytes of the end
+// of the whole input buffer, i.e. the last stream of a batch) takes the range-checked loads.
+// (Tried: every lane asks at every event for the pair at its write pointer, again if its ring had no
+// room -- no predicate around the loads, no state in the registers they return to: 3.30 -> 3.57 ms,
+// the wavefront then waits for 64 lanes' loads at every event.)
+__device__ __forceinline__ void s2_event(SegReader& rd, S2Ck& ck, bool want, bool edge) {
     if (rd.has_a && (uint32_t)kSegInWords - (rd.in_wr - rd.in_rd) >= (uint32_t)(2 * kSegChunk)) {
         rd.put(rd.pend_a);
         rd.put(rd.pend_b);
@@ -232,7 +238,7 @@ __device__ __forceinline__ void s2_event(SegReader& rd, S2Ck& ck, bool want) {
     s2_ck_flush(ck);
     asm volatile("" ::: "memory");
     if (want && !rd.has_a) {
-        if (rd.gp >= rd.buf_lo && rd.gp + 8 * kSegChunk <= rd.buf_hi) {  // one range check for the pair
+        if (!edge) {
             const uint4 va = *reinterpret_cast<const uint4*>(rd.gp);
             const uint4 vb = *reinterpret_cast<const uint4*>(rd.gp + 4 * kSegChunk);
             rd.pend_a.w[0] = va.x;
@@ -330,7 +336,7 @@ __device__ __forceinline__ void s2_guess_scan(const uint32_t* lit, const S2Codes
                                               uint32_t limit, bool active, uint32_t window, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < window;
     while (__any(running)) {
-        s2_event(rd, ck, running);
+        s2_event(rd, ck, running, cd.edge);
         for (int half = 0; half < 2; half++) {
             const bool fast = running && s.pos + kSegGroupBits <= limit && rd.level() >= kSegHalfNeed;
             bool general = running && !fast && rd.level() >= 2;
@@ -355,7 +361,7 @@ __device__ __forceinline__ void s2_tail_scan(const uint32_t* lit, const S2Codes&
     bool parked = false;  // the lane sits on a token that is no literal and waits for the general step
     uint32_t iter = 0;
     while (__any(running)) {
-        s2_event(rd, ck, running);
+        s2_event(rd, ck, running, cd.edge);
         S2PF(1);
         // one group per event: 16 look-ups for the lanes that have the input for it (what an event
         // guarantees), or, when no lane has, 8; a lane that cannot take part takes one token
@@ -395,7 +401,7 @@ __device__ __forceinline__ void s2_head_scan(const uint32_t* lit, const S2Codes&
                                              uint32_t rb, uint32_t limit, bool active, uint32_t x0, S2Scan& s, S2Ck& ck) {
     bool running = active && s.pos < x0;
     while (__any(running)) {
-        s2_event(rd, ck, running);
+        s2_event(rd, ck, running, cd.edge);
         for (int half = 0; half < 2; half++) {
             const bool have = running && rd.level() >= kSegHalfNeed;
             const bool f4 = have && s.pos + kSegGroupBits <= x0;
@@ -437,7 +443,7 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
                                           S2Plan& plan) {
     const int lane = threadIdx.x & (kWave - 1);
     if (sid >= a.n) return false;
-    const S2Codes cd = s2_codes(a);
+    S2Codes cd = s2_codes(a);
 
     // ---- stream set-up (uniform) ----
     const uint64_t i0 = a.in_off[sid], i1 = a.in_off[sid + 1];
@@ -476,6 +482,8 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     rd.lane_off = (uint32_t)lane;
     rd.buf_lo = a.in;
     rd.buf_hi = a.in + a.in_off[a.n];
+    // what a lane may ask for lies less than a ring and two pairs behind the end of its stream
+    cd.edge = uni((uint32_t)(in + ilen + 512 > rd.buf_hi)) != 0;
     rd.gp = in;
     rd.in_wr = rd.in_rd = 0;
     rd.lo = rd.hi = rd.boff = 0;

@@ -87,8 +87,10 @@ enum : uint32_t { RC_OK = 0, RC_EOB = 0x100, RC_STUCK = 0x101 };  // anything el
 #ifdef FDH_DEBUG_TILES
 __device__ uint32_t g_dbg[1 << 16];
 __device__ uint32_t g_dbg_n;
-__device__ unsigned long long g_gstat[16];
-#define GSTAT(k, v) do { if (lane == 0) atomicAdd(&g_gstat[k], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_gstat[24];
+// statistics are collected per stream (member gacc) and added to the global counters once, at its
+// end: an atomic per phase and tile, contended by every wavefront, used to cost more than the phases
+#define GSTAT(k, v) do { gacc[k] += (unsigned long long)(v); } while (0)
 #else
 #define GSTAT(k, v) do { } while (0)
 #endif
@@ -184,6 +186,9 @@ struct InflaterT {
     uint32_t serial_credit;  // tokens to decode serially before the next tile attempt
     uint32_t* span_list;     // scratch of this workgroup: kSpanMaxMatches x {at, length | dist << 16}; null: no spans
     uint32_t span_credit;    // tiles to run before the next span attempt (after a span that did not pay)
+#ifdef FDH_DEBUG_TILES
+    unsigned long long gacc[24] = {};
+#endif
 
     __device__ __forceinline__ InflaterT(TableSetT<LB>& t, WaveIo& w, HeaderScratch* h, int ln)
         : T(t), io(w), hs(h), lane(ln), span_list(nullptr) {}
@@ -873,15 +878,18 @@ struct InflaterT {
                 const bool near = indep && src_lo >= ring_lo;    // wholly in the ring
                 uint32_t b[16];
                 if (__any(far)) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our own flush stores
-                    // every lane issues all 16 loads back to back (idle ones re-read the slot's first
-                    // byte), so the batch costs one round trip, not one per byte
-                    const uint8_t* src = out_al + gmis + (far ? src_lo : 0);
-#pragma unroll
-                    for (uint32_t k = 0; k < 16; k++) {
-                        // L1-bypassing load: the line may have been cached before our later stores
-                        b[k] = __hip_atomic_load(src + ((far && k < length) ? k : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // ONE unaligned 16-B load per match (what lies behind the match's end is older
+                    // output of this stream, i.e. readable); it bypasses the L1, which may hold the
+                    // line as it was before our later stores
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (far) {
+                        const uint8_t* src = out_al + gmis + src_lo;
+                        asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(v) : "v"(src) : "memory");  // (first wait: our own flush stores)
                     }
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) b[k] = (v[k >> 2] >> (8 * (k & 3))) & 0xFFu;
                 }
                 if (near) {
 #pragma unroll
@@ -899,7 +907,7 @@ struct InflaterT {
             }
             wave_sync();
         }
-        TPHASE(7);
+        TPHASE(16);
         // ---- replay the other matches in stream order (sources are final by then) ----
         // descriptors travel in registers (lane j of a batch holds match j0 + j), not through LDS
         for (uint32_t j0 = 0; j0 < nmatch; j0 += kWave) {
@@ -1511,6 +1519,11 @@ struct InflaterT {
         StreamResult r;
         r.ambiguous = false;
         flush(true);
+#ifdef FDH_DEBUG_TILES
+        if (lane == 0)
+            for (int k = 0; k < 24; k++)
+                if (gacc[k]) atomicAdd(&g_gstat[k], gacc[k]);
+#endif
         uint32_t adler = (adler_b << 16) | adler_a;
         if (rc == RC_OK) {
             r.status = (!(flags & 1u) && stored != adler) ? (uint32_t)ST_WRONG_CHECKSUM : (uint32_t)ST_OK;

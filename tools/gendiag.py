@@ -52,7 +52,7 @@ for flags in flag_sets:
     import ctypes as C
     Lc = _lib.lib()
     if hasattr(Lc, "fdh_debug_read_gstat"):
-        g = (C.c_ulonglong * 16)()
+        g = (C.c_ulonglong * 24)()
         Lc.fdh_debug_read_gstat(g, 1)
         fd.inflate_batch(comp, c_off, out, r_off, ol, st, ad, flags=flags)
         torch.cuda.synchronize()
