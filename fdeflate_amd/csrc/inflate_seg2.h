@@ -454,7 +454,8 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
     bool ours = ilen < (1ull << 19) && ocap < (1ull << 24) && ilen * 8 >= a.canon_bits + 44ull;
     const uint32_t in_bits = (uint32_t)(ilen * 8);
     const uint32_t cap = (uint32_t)ocap;
-    if (ours) {  // canonical prefix: lane k compares stream dword k
+    bool canonical = true;
+    if (ilen * 8 >= a.canon_bits + 44ull) {  // canonical prefix: lane k compares stream dword k (a shorter stream cannot be one)
         bool mismatch = false;
         if (lane < 14) {
             uint32_t v = 0;
@@ -463,10 +464,21 @@ __device__ __forceinline__ bool seg2_plan(const SegArgs& a, const uint32_t* lit,
             if (lane == 13) v &= (1u << (a.canon_bits - 13 * 32)) - 1;
             mismatch = v != a.canon_hdr[lane];
         }
-        ours = !__any(mismatch);
+        canonical = !__any(mismatch);
+    } else {
+        canonical = false;
     }
+    ours = ours && canonical;
     if (!ours) {
-        if (lane == 0) seg_leave_pending(a, sid);
+        if (lane == 0) {
+            if (!canonical && a.list2) {  // not for the segment kernel either: straight to the kernels behind it
+                a.status[sid] = a.pending;
+                const uint32_t k = atomicAdd(&a.list2[0], 1u);
+                a.list2[4 + k] = (uint32_t)sid;
+            } else {
+                seg_leave_pending(a, sid);
+            }
+        }
         return false;
     }
     const uint32_t data_bits = in_bits - a.canon_bits;
@@ -1085,16 +1097,20 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
     }
 }
 
-__device__ __forceinline__ void seg2_decode(const SegArgs& a, Seg2Lds& L, uint2* ckpt, const uint64_t sid) {
+// False: the stream was passed on at once (not canonical / out of range) or after the counting pass.
+__device__ __forceinline__ bool seg2_decode(const SegArgs& a, Seg2Lds& L, uint2* ckpt, const uint64_t sid) {
     const uint32_t wid = threadIdx.x / kWave;
     uint32_t* A = L.a + wid * kS2AWords;
     uint32_t* B = L.b + wid * kS2BWords;
     S2Plan plan;
 #ifdef FDH_S2_SKIP_WRITE
-    if (seg2_plan(a, L.lit, A, ckpt, sid, plan) && (threadIdx.x & 63) == 0) seg_leave_pending(a, sid);
+    const bool planned = seg2_plan(a, L.lit, A, ckpt, sid, plan);
+    if (planned && (threadIdx.x & 63) == 0) seg_leave_pending(a, sid);
 #else
-    if (seg2_plan(a, L.lit, A, ckpt, sid, plan)) seg2_write(a, L.lit, A, B, ckpt, sid, plan);
+    const bool planned = seg2_plan(a, L.lit, A, ckpt, sid, plan);
+    if (planned) seg2_write(a, L.lit, A, B, ckpt, sid, plan);
 #endif
+    return planned;
 }
 
 }  // namespace fdh

@@ -146,6 +146,8 @@ struct SegArgs {
     uint2* ckpt;     // interval decoder (inflate_seg2.h): checkpoint scratch, kS2CkptPerWave entries per wavefront
     const uint32_t* canon_nl;  // ... and the canonical bookkeeping of the symbols >= 256 (CanonTables::nl)
     const uint32_t* canon_lit2;  // ... and its decode table (CanonTables::lit2)
+    uint32_t* list2; // nullable (interval kernel): the list of the kernel BEHIND the segment kernel -- streams without
+                     // the ultra-fast prefix go there directly, the segment kernel would only look at them and pass them on
 };
 
 // Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).
