@@ -355,6 +355,31 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
     }
 }
 
+// Hand-out order of a batch for persistent wavefronts: the streams of at least half the mean length
+// from the front, the shorter ones from the back (each class roughly in batch order: one atomic per
+// wavefront and class).  A kernel ends when its last long stream does, and while the long streams
+// drain the wavefronts that have run out of work take the short ones instead of idling (the bench
+// batch: every 16th stream 0.5 KB, every 16th half the size).  counters: [0] long, [1] short, zeroed.
+__global__ __launch_bounds__(256) void stream_order_kernel(const uint64_t* in_off, uint32_t n, uint32_t* order, uint32_t* counters) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t thr = (in_off[n] - in_off[0]) / n / 2;
+    const bool valid = i < n;
+    const bool big = valid && (in_off[i + 1] - in_off[i]) >= thr;
+    const bool small = valid && !big;
+    const uint64_t mb = __ballot(big), ms = __ballot(small);
+    uint32_t base_b = 0, base_s = 0;
+    if (lane == 0) {
+        if (mb) base_b = atomicAdd(&counters[0], (uint32_t)__popcll(mb));
+        if (ms) base_s = atomicAdd(&counters[1], (uint32_t)__popcll(ms));
+    }
+    base_b = __shfl(base_b, 0);
+    base_s = __shfl(base_s, 0);
+    const uint64_t below = (1ull << lane) - 1;
+    if (big) order[base_b + (uint32_t)__popcll(mb & below)] = i;
+    if (small) order[n - 1 - (base_s + (uint32_t)__popcll(ms & below))] = i;
+}
+
 // Canonical streams, counted by segments and written by intervals (inflate_seg2.h): one stream per
 // wavefront, one workgroup of 16 persistent wavefronts per CU with all of its LDS.
 __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArgs a) {
@@ -389,7 +414,7 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
             if (cur >= n32) break;
             end = min(n32, cur + take);
         }
-        took = seg2_decode(a, lds, ckpt, cur) || took;
+        took = seg2_decode(a, lds, ckpt, a.order ? uni(a.order[cur]) : cur) || took;
         cur++;
     }
 }
@@ -634,27 +659,40 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         }
         const bool seg2 = !(flags & 0x400u);
         const unsigned s2blocks = std::min((unsigned)((n + fdh::kS2Waves - 1) / fdh::kS2Waves), (unsigned)cus);
-        const size_t list_words = 2 * (size_t)(n + 4);
+        // (+ the hand-out order of the interval kernel when every wavefront gets several streams);
+        // layout: first list | 4 words: counters of stream_order_kernel | second list | order | checkpoints
+        const bool ordered = seg2 && n >= 4ull * s2blocks * fdh::kS2Waves && n <= 0x7FFFFFFFull;
+        const size_t list2_at = (size_t)(n + 4) + 4;
+        const size_t list_words = list2_at + (size_t)(n + 4) + (ordered ? (size_t)((n + 1) & ~1ull) : 0);
         const size_t ckpt_bytes = seg2 ? (size_t)s2blocks * fdh::kS2Waves * fdh::kS2CkptPerWave * sizeof(uint2) : 0;
         if (hipMallocAsync(reinterpret_cast<void**>(&list), list_words * sizeof(uint32_t) + ckpt_bytes, stream) != hipSuccess) {
             (void)hipGetLastError();
             list = nullptr;  // fall back to the status-scan form
         } else {
             e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
-            if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 4 * sizeof(uint32_t), stream);
+            if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 8 * sizeof(uint32_t), stream);  // counters + second header
             if (e != hipSuccess) return (int)e;
         }
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->len4, canon->hdr,
-                        fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr, canon->nl, canon->lit2, nullptr};
+                        fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr, canon->nl, canon->lit2, nullptr, nullptr};
         if (list && seg2) {  // interval kernel first; what it leaves goes through the segment kernel
             sa.ckpt = reinterpret_cast<uint2*>(list + list_words);
-            sa.list2 = list + (n + 4);
+            sa.list2 = list + list2_at;
+            if (ordered) {
+                uint32_t* order = list + list2_at + (n + 4);
+                uint32_t* counters = list + (n + 4);
+                hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in_off, (uint32_t)n, order, counters);
+                e = hipGetLastError();
+                if (e != hipSuccess) return (int)e;
+                sa.order = order;
+            }
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
             e = hipGetLastError();
             if (e != hipSuccess) return (int)e;
             sa.src_list = list;
-            sa.list = list + (n + 4);
+            sa.list = list + list2_at;
             sa.list2 = nullptr;
+            sa.order = nullptr;
             if (flags & 0x800u) {  // debug: the interval kernel only
                 (void)hipFreeAsync(list, stream);
                 return 0;

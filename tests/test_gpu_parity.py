@@ -475,6 +475,59 @@ def test_mixed_batch_at_scale(harness):
     harness.assert_inflate_parity(names, blobs, caps)
 
 
+def test_ragged_batch_handed_out_long_streams_first(harness):
+    """20 000 ultra-fast streams of very different lengths in one batch (most short, every eighth
+    long, some empty, a few non-canonical ones in between): with several streams per persistent
+    wavefront the interval kernel hands them out long ones first (stream_order_kernel) and sends the
+    non-canonical ones straight to the general kernels' list.  Encode on the GPU, decode, compare
+    with the raw bytes; the checksum the decoder reports must be the trailer the encoder wrote."""
+    import torch
+    import zlib
+    import fdeflate_amd as fd
+    r = np.random.default_rng(2026)
+    n = 20000
+    lens = r.integers(0, 3000, n)
+    lens[::8] = r.integers(20000, 60000, len(lens[::8]))
+    lens[5::97] = 0
+    total = int(lens.sum())
+    raw_h = r.integers(0, 256, total, dtype=np.uint8)
+    raw_h[r.random(total) < 0.6] = 0
+    r_off_h = np.zeros(n + 1, dtype=np.int64)
+    r_off_h[1:] = np.cumsum(lens)
+    raw = torch.from_numpy(raw_h).cuda()
+    r_off = torch.from_numpy(r_off_h).cuda()
+    bounds = np.array([(fd.ultrafast_bound(int(x)) + 15) & ~15 for x in lens], dtype=np.int64)
+    c_off_h = np.zeros(n + 1, dtype=np.int64)
+    c_off_h[1:] = np.cumsum(bounds)
+    c_off = torch.from_numpy(c_off_h).cuda()
+    comp = torch.zeros(int(c_off_h[-1]), dtype=torch.uint8, device="cuda")
+    clen = fd.deflate_ultrafast_batch(raw, r_off, comp, c_off)
+    # every 501st stream is replaced by a zlib level-6 stream of the same bytes (fits the slot: the
+    # ultra-fast bound is larger than anything zlib produces for these sizes)
+    comp_h = comp.cpu().numpy()
+    clen_h = clen.cpu().numpy().astype(np.int64)
+    swapped = list(range(3, n, 501))
+    for i in swapped:
+        z = zlib.compress(raw_h[r_off_h[i]:r_off_h[i + 1]].tobytes(), 6)
+        assert len(z) <= bounds[i]
+        comp_h[c_off_h[i]:c_off_h[i] + bounds[i]] = 0
+        comp_h[c_off_h[i]:c_off_h[i] + len(z)] = np.frombuffer(z, dtype=np.uint8)
+        clen_h[i] = len(z)
+    comp = torch.from_numpy(comp_h).cuda()
+    for flags in (0, fd.api.FLAG_NO_INTERVALS):
+        out = torch.full((total + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        out_len, status, adler = fd.inflate_batch(comp, c_off, out, r_off, flags=flags)
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0, flags
+        assert torch.equal(out_len.to(torch.int64), torch.from_numpy(lens).cuda()), flags
+        assert torch.equal(out[:total], raw), flags
+        assert bool((out[total:] == 0xA5).all()), flags
+        ad = adler.cpu().numpy().view(np.uint32)
+        for i in list(range(0, n, 997)) + swapped[:5]:
+            t = comp_h[c_off_h[i] + clen_h[i] - 4:c_off_h[i] + clen_h[i]]
+            assert int(ad[i]) == int.from_bytes(t.tobytes(), "big"), (flags, i)
+
+
 def test_batch_roundtrip_at_scale(harness):
     """4096 x 64 KiB: encode on the GPU, decode on the GPU; every stream Ok, lengths exact,
     decoded == raw, and the Adler-32 the decoder reports equals the trailer the encoder wrote
