@@ -568,6 +568,32 @@ def main():
                              "ms_per_step": round(w4 * 1e3 / psteps, 4), "steps": psteps,
                              "roofline": roofline(palg, sum(k4) / len(k4), "inflate_seg2_kernel + png_pipe_kernel",
                                                   profiled_traffic("png") if full else None)})
+                # ... and the other direction: filtering fused into the ultra-fast encoder (the pixels just
+                # reconstructed, the rows' own filter types): must give the bench's compressed streams back
+                try:
+                    types = out.view(n, rows_png, rb_png + 1)[:, :, 0].contiguous().view(-1)
+                    t_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * rows_png
+                    fenc = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+
+                    def fenc_step():
+                        return fd.png_filter_deflate_ultrafast_batch(pix, p_off, types, t_off, fenc, enc_off, rb_png, bpp_png)
+
+                    flen, fstat = fenc_step()
+                    barrier()
+                    assert int(fstat.abs().sum()) == 0 and torch.equal(flen.to(torch.int64), clen), "fused filter + encode lengths"
+                    for i in (0, 7, 15, n - 1):
+                        a0, b0 = i * bound, int(c_off[i])
+                        assert torch.equal(fenc[a0:a0 + int(clen[i])], comp[b0:b0 + int(clen[i])]), "fused filter + encode bytes"
+                    w5, k5 = time_steps(fenc_step, psteps, 1, barrier)
+                    falg = n * rows_png * rb_png + n * rows_png + in_bytes + 8 * n
+                    also.append({"workload": "SURVEY 8f: PNG filtering fused into the ultra-fast encoder "
+                                             "(fdh_png_filter_deflate_ultrafast_batch) of the %d images" % n,
+                                 "metric": "input GB/s", "value": round(n * rows_png * rb_png / (w5 / psteps) / 1e9, 3),
+                                 "ms_per_step": round(w5 * 1e3 / psteps, 4), "steps": psteps,
+                                 "roofline": roofline(falg, sum(k5) / len(k5), "deflate_ultrafast_kernel_t<true>", None)})
+                    del fenc, types
+                except Exception as e:
+                    also.append({"workload": "SURVEY 8f: PNG filter + ultra-fast encode", "error": repr(e)})
                 del pix
             except KeyError:
                 pass

@@ -142,4 +142,8 @@ if hasattr(Lc, "fdh_debug_s2time"):
             print("    tail: %-30s %8.0f" % (nm, t2[sel, k].mean()))
     for kind in (7, 15):
         selk = np.array([i for i in range(m) if i % 16 == kind])
-        print("  kind %d streams: total %.0f cycles (write %.0f)" % (kind, d[selk].sum(axis=1).mean(), d[selk, 4].mean()))
+        print("  kind %d streams (%s): total %.0f cycles: %s" % (
+            kind, "half zero" if kind == 7 else "all zero", d[selk].sum(axis=1).mean(),
+            ", ".join("%s %.0f" % (nm, d[selk, k].mean()) for k, nm in enumerate(names))))
+        print("      write pass: " + ", ".join("%s %.0f" % (nm.split(":")[0][:18], acc[selk, k].mean()) for k, nm in enumerate(wn)))
+        print("      tail scan:  " + ", ".join("%s %.0f" % (nm, t2[selk, k].mean()) for k, nm in enumerate(tn) if nm))
