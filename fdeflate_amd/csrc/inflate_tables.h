@@ -41,14 +41,27 @@ struct CodeBook {
     uint32_t run[16];    // scratch: symbols of each length placed so far
 };
 
+// Extra bits / base of a length symbol (i = symbol - 257) and of a distance symbol, computed: the
+// RFC-1951 tables (kLenBase / kLenExtra / kDistBase / kDistExtra, reference src/tables.rs:68-88) are
+// arithmetic progressions, and a table in memory is a trip to the cache in the middle of a token.
+__device__ __forceinline__ uint32_t len_extra_base(uint32_t i) {  // extra | base << 8
+    const uint32_t e = (i < 8 || i == 28) ? 0u : (i >> 2) - 1;
+    const uint32_t b = i == 28 ? 258u : (i < 8 ? 3 + i : 3 + ((4 + (i & 3)) << e));
+    return e | (b << 8);
+}
+__device__ __forceinline__ uint32_t dist_extra_base(uint32_t sym) {  // extra | base << 8
+    const uint32_t e = sym < 4 ? 0u : (sym >> 1) - 1;
+    const uint32_t b = sym < 4 ? sym + 1 : 1 + ((2 + (sym & 1)) << e);
+    return e | (b << 8);
+}
+
 template <int LB>
 struct LitlenTraitsT {
     static constexpr int kBits = LB;
     __device__ static uint32_t entry(uint32_t sym, uint32_t nb) {
         if (sym < 256) return nb | (K_LIT1 << 4) | (sym << 8) | (nb << 24);
         if (sym == 256 || sym >= 286) return nb | (K_EOB << 4);  // 286/287: parity trap 1
-        return nb | (K_LEN << 4) | ((uint32_t)kLenExtra[sym - 257] << 8) |
-               ((uint32_t)kLenBase[sym - 257] << 16);
+        return nb | (K_LEN << 4) | (len_extra_base(sym - 257) << 8);  // extra in [12:8], base in [31:16]
     }
     __device__ static uint32_t long_entry() { return K_LONG << 4; }
 };
@@ -57,7 +70,7 @@ struct DistTraits {
     static constexpr int kBits = kDistBits;
     __device__ static uint32_t entry(uint32_t sym, uint32_t nb) {
         if (sym >= 30) return nb | (D_INVALID << 4);  // tables.rs:130-140: slots 30,31 are 0
-        return nb | (D_DIST << 4) | ((uint32_t)kDistExtra[sym] << 8) | ((uint32_t)kDistBase[sym] << 16);
+        return nb | (D_DIST << 4) | (dist_extra_base(sym) << 8);  // extra in [11:8], base in [31:16]
     }
     __device__ static uint32_t long_entry() { return D_LONG << 4; }
 };
@@ -153,6 +166,11 @@ __device__ __forceinline__ int build_table(uint32_t* table, const uint8_t* lens,
         }
     }
     wave_sync();
+    // The placement counters have done their work: run[l] now holds the left-justified 16-bit bound of the
+    // codes of length <= l (canonical codes of one length are consecutive and the lengths follow each
+    // other), which is what long_walk counts against.
+    if (lane >= 1 && lane < 16) cb.run[lane] = (cb.first[lane] + cb.hist[lane]) << (16 - lane);
+    wave_sync();
     return BUILD_OK;
 }
 
@@ -202,16 +220,18 @@ __device__ __forceinline__ void long_decode(const CodeBook& cb, const uint16_t* 
 // complete code).
 __device__ __forceinline__ bool long_walk(const CodeBook& cb, const uint16_t* sorted, uint32_t w, int min_len,
                                           uint32_t& sym, uint32_t& nbits) {
-    const uint32_t r = __brev(w);  // canonical codes are compared MSB first
-    for (int len = min_len; len <= 15; len++) {
-        const uint32_t d = (r >> (32 - len)) - cb.first[len];
-        if (d < cb.hist[len]) {
-            sym = sorted[cb.offs[len] + d];
-            nbits = (uint32_t)len;
-            return true;
-        }
-    }
-    return false;
+    // Canonical codes compared MSB first: the length of the code in front of r16 is the number of
+    // bounds (CodeBook::run after build_table) it has passed -- no loop with an exit per lane, the
+    // lanes of a wavefront sit on codes of different lengths.
+    const uint32_t r16 = __brev(w) >> 16;
+    uint32_t len = (uint32_t)min_len;
+#pragma unroll
+    for (int l = min_len; l < 15; l++) len += r16 >= uni(cb.run[l]) ? 1u : 0u;
+    if (r16 >= uni(cb.run[15])) return false;
+    const uint32_t d = (r16 >> (16 - len)) - cb.first[len];
+    sym = sorted[cb.offs[len] + d];
+    nbits = len;
+    return true;
 }
 
 }  // namespace fdh
