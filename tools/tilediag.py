@@ -71,7 +71,9 @@ if hasattr(lib, "fdh_debug_read_gstat"):
           % (g[0] / n, g[1] / tiles, g[5] / n, g[3] / n, g[9] / n, g[15] / n))
     print("cycles per stream: tiles %.0f, serial %.0f, headers %.0f" % (g[2] / n, g[7] / n, g[8] / n))
     names = {10: "pass 1 (guessed chains)", 11: "synchronisation (%.1f iterations per tile)" % (g[6] / tiles),
-             12: "counts + prefix sums", 13: "literals, match list", 16: "matches with final sources, 64 at a time", 14: "matches replayed in order"}
+             12: "counts + prefix sums", 13: "literals, match list", 16: "matches with sources older than the ring", 14: "the other matches (rounds, one by one)"}
+    print("matches per tile: %.1f, copied in %.1f rounds (%.1f per round) and %.1f one by one"
+          % (g[15] / tiles, g[19] / tiles, g[21] / max(g[19], 1), g[20] / tiles))
     print("cycles per tile:")
     for k in (10, 11, 12, 13, 16, 14):
         print("   %-44s %8.0f" % (names[k], g[k] / tiles))
