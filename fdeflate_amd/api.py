@@ -82,6 +82,10 @@ class Decompressor:
     def is_done(self):
         return bool(self._L.fdh_decompressor_is_done(self._d))
 
+    def attempts(self):
+        """Decode attempts made so far (introspection, fdh_decompressor_attempts)."""
+        return int(self._L.fdh_decompressor_attempts(self._d))
+
     def read(self, data, output, output_position):
         data = bytes(data)
         mv = memoryview(output)

@@ -17,6 +17,11 @@
 //     front of output_position are not needed (each attempt decodes from the start of the stream,
 //     the LZ77 history lives in the device slot).
 //
+// Draining through a small output window: an attempt decodes AHEAD of what the caller can take (slot =
+// twice what has been delivered + 64 KiB) and the following calls are served from that prefix, so a
+// stream of N bytes costs O(N) decoded bytes however small the window (round 2: O(N^2 / window)).  A
+// hard error in the part decoded ahead is not reported early: the attempt is repeated with the exact
+// slot, whose classification is the reference's.
 // Re-decoding the prefix on every call would be quadratic for a large stream fed in small pieces;
 // above kAlwaysBelow buffered bytes an attempt is made only once the stream has grown by 1/8 --
 // or when the caller passes an empty `input`, which is how both the reference's test harness
@@ -85,6 +90,14 @@ struct fdh_decompressor {
     bool tried = false;
     uint32_t error = 0;       // sticky DecompressionError (status code), 0 = none
     int device = 0;
+    // What the last attempt left in the device slot BEYOND what the caller could take: an attempt
+    // decodes ahead (into a slot of twice what has been delivered + 64 KiB), and the calls that follow
+    // are served from that prefix without decoding anything -- draining a stream of N bytes through a
+    // small window then costs O(N) decoded bytes, not O(N^2 / window).
+    size_t ahead_have = 0;    // valid decoded prefix in the device slot
+    size_t ahead_in = 0;      // in_len it was decoded from
+    uint32_t ahead_st = 0;    // the status of that attempt (for ITS slot)
+    uint64_t attempts = 0;    // decode attempts so far (introspection)
 };
 
 extern "C" {
@@ -102,6 +115,8 @@ void fdh_decompressor_ignore_adler32(fdh_decompressor* d) {
 }
 
 int fdh_decompressor_is_done(const fdh_decompressor* d) { return d && d->done ? 1 : 0; }
+
+uint64_t fdh_decompressor_attempts(const fdh_decompressor* d) { return d ? d->attempts : 0; }
 
 int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t input_len, uint8_t* output,
                           size_t output_len, size_t output_position, size_t* consumed, size_t* produced,
@@ -147,57 +162,93 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     *consumed = input_len;
 
     const size_t room = output_len - output_position;
+    // Hands n bytes of the decoded prefix to the caller and says what state that leaves: the prefix
+    // used up -> the status of the attempt that made it applies; otherwise the caller's buffer is full
+    // "but there are more bytes to output".
+    auto deliver = [&](size_t n) -> int {
+        if (n) {
+            hipError_t e_ = hipMemcpy(output + output_position, d->out.p + d->delivered, n, hipMemcpyDeviceToHost);
+            if (e_ != hipSuccess) return fail(FDH_ERR_HIP, std::string("hipMemcpy(decoded bytes): ") + hipGetErrorString(e_));
+            d->delivered += n;
+            *produced = n;
+        }
+        d->output_limited = false;
+        if (d->delivered < d->ahead_have) {
+            d->output_limited = true;
+            return FDH_SUCCESS;
+        }
+        switch (d->ahead_st) {
+            case FDH_STREAM_OK:
+                d->done = true;
+                break;
+            case FDH_OUTPUT_TOO_LARGE:
+                d->output_limited = true;  // "the output is full but there are more bytes to output"
+                break;
+            case FDH_INSUFFICIENT_INPUT:
+                // Ok with is_done() == false: wait for more input (input that arrived after the prefix was
+                // decoded may hold more bytes for a window that is full now)
+                d->output_limited = d->in_len != d->ahead_in && n == room;
+                break;
+            default:
+                d->error = d->ahead_st;    // a DecompressionError: sticky, like the reference's poisoned state
+                *stream_status = d->ahead_st;
+                break;
+        }
+        return FDH_SUCCESS;
+    };
+    const size_t avail = d->ahead_have > d->delivered ? d->ahead_have - d->delivered : 0;
+    if (d->tried && avail > 0) {
+        // the decoded prefix fills the window, or holds all the reference could have produced from this input
+        const bool final_prefix = d->in_len == d->ahead_in && d->ahead_st != FDH_OUTPUT_TOO_LARGE;
+        if (avail >= room || final_prefix) return deliver(std::min(room, avail));
+    }
     // is a decode attempt worth it?  (nothing new and not output-limited -> no)
     const bool grew = d->in_len != d->attempted_in;
     const bool flush = input_len == 0;
     bool attempt = !d->tried || d->output_limited || (grew && (flush || d->in_len < kAlwaysBelow ||
                                                                d->in_len >= d->attempted_in + d->attempted_in / 8));
     if (d->tried && d->output_limited && room == 0) attempt = false;  // still nowhere to put a byte
-    if (!attempt) return FDH_SUCCESS;
+    if (!attempt) return FDH_SUCCESS;  // (nothing of the prefix is left over here: that state is output-limited)
 
-    size_t cap = d->delivered + room;
-    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-    HIP_TRY(d->out.reserve(cap + 16, 0));
+    const size_t cap_exact = std::min<size_t>(d->delivered + room, 0xFFFFFFF0ull);
+    size_t cap = std::min<size_t>(std::max<size_t>(cap_exact, 2 * d->delivered + 65536), 0xFFFFFFF0ull);
     HIP_TRY(d->meta.reserve(64, 0));
-    uint64_t meta[8] = {0, (uint64_t)d->in_len, 0, (uint64_t)cap, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(d->meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
-    uint64_t* m = reinterpret_cast<uint64_t*>(d->meta.p);
-    uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
     // a hipMalloc'd buffer can be empty only before the first byte arrives
     HIP_TRY(d->in.reserve(16, d->in_len));
-    int rc = fdh_inflate_batch(d->in.p, m, d->out.p, m + 2, res, res + 1, res + 2, 1,
-                               d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u, nullptr);
-    if (rc != FDH_SUCCESS) return rc;
     uint32_t host_res[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost));  // synchronises the null stream
+    for (;;) {
+        HIP_TRY(d->out.reserve(cap + 16, 0));  // (every attempt decodes from the first byte: nothing to keep)
+        uint64_t meta[8] = {0, (uint64_t)d->in_len, 0, (uint64_t)cap, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(d->meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
+        uint64_t* m = reinterpret_cast<uint64_t*>(d->meta.p);
+        uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
+        int rc = fdh_inflate_batch(d->in.p, m, d->out.p, m + 2, res, res + 1, res + 2, 1,
+                                   d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u, nullptr);
+        if (rc != FDH_SUCCESS) return rc;
+        HIP_TRY(hipMemcpy(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost));  // synchronises the null stream
+        d->attempts++;
+        const uint32_t st1 = host_res[1];
+        const bool classified = st1 == FDH_STREAM_OK || st1 == FDH_WRONG_CHECKSUM || st1 == FDH_OUTPUT_TOO_LARGE ||
+                                st1 == FDH_INSUFFICIENT_INPUT;
+        // a hard error somewhere in the part decoded ahead: the caller must not hear of it before its
+        // window gets there -- decode again into exactly what the caller can take
+        if (!classified && cap != cap_exact) {
+            cap = cap_exact;
+            continue;
+        }
+        break;
+    }
     const uint32_t st = host_res[1];
     d->tried = true;
     d->attempted_in = d->in_len;
-    d->output_limited = false;
     size_t have = 0;  // valid prefix of the decoded stream in the device slot
     if (st == FDH_STREAM_OK || st == FDH_WRONG_CHECKSUM || st == FDH_OUTPUT_TOO_LARGE || st == FDH_INSUFFICIENT_INPUT) {
         have = std::min<size_t>(host_res[0], cap);
     }
-    if (have > d->delivered) {
-        const size_t n = have - d->delivered;  // <= room by construction
-        HIP_TRY(hipMemcpy(output + output_position, d->out.p + d->delivered, n, hipMemcpyDeviceToHost));
-        d->delivered = have;
-        *produced = n;
-    }
-    switch (st) {
-        case FDH_STREAM_OK:
-            d->done = true;
-            break;
-        case FDH_OUTPUT_TOO_LARGE:
-            d->output_limited = true;  // "the output is full but there are more bytes to output"
-            break;
-        case FDH_INSUFFICIENT_INPUT:
-            break;                     // Ok with is_done() == false: wait for more input
-        default:
-            d->error = st;             // a DecompressionError: sticky, like the reference's poisoned state
-            *stream_status = st;
-            break;
-    }
+    d->ahead_have = std::max(have, d->delivered);
+    d->ahead_in = d->in_len;
+    d->ahead_st = st;
+    return deliver(std::min(room, d->ahead_have - d->delivered));
     return FDH_SUCCESS;
 #undef HIP_TRY
 }

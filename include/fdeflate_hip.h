@@ -226,6 +226,9 @@ fdh_decompressor *fdh_decompressor_new(void);
 void fdh_decompressor_free(fdh_decompressor *d);
 void fdh_decompressor_ignore_adler32(fdh_decompressor *d);
 int fdh_decompressor_is_done(const fdh_decompressor *d);
+/* Introspection: decode attempts made so far (a stream drained through a small window needs O(log) of
+ * them: every attempt decodes ahead of what the caller can take, see fdh_decompressor_read). */
+uint64_t fdh_decompressor_attempts(const fdh_decompressor *d);
 int fdh_decompressor_read(fdh_decompressor *d, const uint8_t *input, size_t input_len,
                           uint8_t *output, size_t output_len, size_t output_position,
                           size_t *consumed, size_t *produced, uint32_t *stream_status);

@@ -306,3 +306,63 @@ def test_bounded_output_with_history_compaction(fd):
             buf[:keep] = buf[pos - keep:pos]
             pos = keep
     assert bytes(got) == raw
+
+
+def test_large_stream_through_a_small_window_decodes_ahead(fd):
+    """A 3 MB multi-block stream with the whole input at hand, drained through a 16 KiB window (the
+    png-crate pattern with history compaction): bytes and end state as the oracle's, and the number
+    of decode attempts stays logarithmic -- every attempt decodes ahead of what the caller can take
+    and the following calls are served from that prefix (one attempt per call would be ~190 decodes
+    of ever longer prefixes).  Then the same with a wrong checksum: the error arrives with the last
+    bytes, not before, and a hard error in the middle of the stream arrives only when the window
+    gets there."""
+    r = np.random.default_rng(77)
+    raw = bytes((np.cumsum(r.integers(-3, 4, size=3_000_000)) & 0xFF).astype(np.uint8))
+    comp = zlib.compress(raw, 6)
+
+    def drain(data, window=16_384):
+        d = fd.Decompressor()
+        got = bytearray()
+        buf = bytearray(32_768 + window)
+        pos = 0
+        fed = False
+        status = 0
+        calls = 0
+        while not d.is_done():
+            calls += 1
+            assert calls < 5000
+            try:
+                c, p = d.read(b"" if fed else data, buf, pos)
+            except fd.DecompressionError as e:
+                status = e.status
+                break
+            fed = True
+            got += buf[pos:pos + p]
+            pos += p
+            if p == 0 and pos < len(buf):
+                break                      # nothing more without more input
+            if pos > 32_768:               # keep 32 KiB of history in front, as png does
+                buf[:32_768] = buf[pos - 32_768:pos]
+                pos = 32_768
+        return status, bytes(got), d.attempts(), calls
+
+    st, got, attempts, calls = drain(comp)
+    assert st == 0 and got == raw
+    assert calls > 150 and attempts <= 12, (calls, attempts)
+    # wrong checksum: every byte is delivered, the error comes with the end of the stream
+    bad = bytearray(comp); bad[-1] ^= 0x55
+    st, got, attempts, _ = drain(bytes(bad))
+    # (like the reference's Err, the call that fails does not say how much it produced: its bytes are lost to
+    # a caller that goes by the return value)
+    assert fd.STATUS_NAMES[st] == "WrongChecksum" and attempts <= 12
+    assert raw.startswith(got) and len(got) >= len(raw) - 16_384
+    # a flipped bit in the middle: the bytes in front of the damage are delivered first
+    mid = bytearray(comp); mid[len(comp) // 2] ^= 0x10
+    st, got, attempts, _ = drain(bytes(mid))
+    est, _, _ = ob.decompress_bounded(bytes(mid), 4_000_000)   # the one-shot classification of the whole input
+    _, eout = ob.decompress_by_chunks(bytes(mid), 0, 4_000_000)   # ... and what the reference had produced by then
+    assert st == est, (st, est)
+    if est == 0:
+        assert got == eout
+    else:
+        assert eout.startswith(got) and len(got) >= len(eout) - 16_384 and len(got) > 500_000
