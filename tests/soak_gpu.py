@@ -168,10 +168,52 @@ def uf_round(seed):
                 assert int(ol[2 * i]) == len(eout) and h[starts[i]:starts[i] + len(eout)].tobytes() == eout and int(ad[2 * i]) == ead, (seed, flags, i)
 
 
+def order_round(seed):
+    """A batch large enough for the interval kernel's hand-out order (several streams per persistent
+    wavefront): ~17 000 ultra-fast streams of random lengths, a random share of them long, a few
+    replaced by zlib streams; encoded on the GPU (bit-exact with the oracle elsewhere), decoded,
+    compared with the raw bytes, checksums against the trailers."""
+    r = np.random.default_rng(seed)
+    n = 16384 + int(r.integers(0, 2000))
+    lens = r.integers(0, int(r.choice([300, 2000, 6000])), n)
+    k = int(r.choice([4, 8, 32]))
+    lens[::k] = r.integers(8000, 50000, len(lens[::k]))
+    total = int(lens.sum())
+    raw_h = r.integers(0, 256, total, dtype=np.uint8)
+    raw_h[r.random(total) < float(r.choice([0.2, 0.7, 0.95]))] = 0
+    r_off_h = np.zeros(n + 1, dtype=np.int64); r_off_h[1:] = np.cumsum(lens)
+    bounds = ((np.array([fd.ultrafast_bound(int(x)) for x in lens], dtype=np.int64) + 15) & ~15)
+    c_off_h = np.zeros(n + 1, dtype=np.int64); c_off_h[1:] = np.cumsum(bounds)
+    raw, r_off, c_off = torch.from_numpy(raw_h).cuda(), torch.from_numpy(r_off_h).cuda(), torch.from_numpy(c_off_h).cuda()
+    comp = torch.zeros(int(c_off_h[-1]), dtype=torch.uint8, device="cuda")
+    clen = fd.deflate_ultrafast_batch(raw, r_off, comp, c_off).cpu().numpy().astype(np.int64)
+    comp_h = comp.cpu().numpy()
+    for i in r.integers(0, n, 12):
+        z = zlib.compress(raw_h[r_off_h[i]:r_off_h[i + 1]].tobytes(), int(r.integers(1, 10)))
+        if len(z) <= bounds[i]:
+            comp_h[c_off_h[i]:c_off_h[i] + bounds[i]] = 0
+            comp_h[c_off_h[i]:c_off_h[i] + len(z)] = np.frombuffer(z, dtype=np.uint8)
+            clen[i] = len(z)
+    comp = torch.from_numpy(comp_h).cuda()
+    out = torch.full((total + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    ol, st, ad = fd.inflate_batch(comp, c_off, out, r_off)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0, seed
+    assert torch.equal(ol.to(torch.int64), torch.from_numpy(lens).cuda()), seed
+    assert torch.equal(out[:total], raw) and bool((out[total:] == 0xA5).all()), seed
+    adh = ad.cpu().numpy().view(np.uint32)
+    for i in r.integers(0, n, 64):
+        t = comp_h[c_off_h[i] + clen[i] - 4:c_off_h[i] + clen[i]]
+        assert int(adh[i]) == int.from_bytes(t.tobytes(), "big"), (seed, i)
+
+
 ONLY = os.environ.get("FDH_SOAK_ONLY", "")
 for s in range(int(sys.argv[1]), int(sys.argv[2])):
-    if ONLY != "uf":
+    if ONLY not in ("uf", "order"):
         enc_round(1000 + s); png_round(2000 + s); dec_round(3000 + s)
-    uf_round(4000 + s)
+    if ONLY != "order":
+        uf_round(4000 + s)
+    if s % 8 == 0 or ONLY == "order":
+        order_round(5000 + s)
     print("seed", s, "ok", flush=True)
 print("SOAK OK")
