@@ -51,6 +51,8 @@ extern "C" {
     pub fn fdh_decompressor_free(d: *mut fdh_decompressor);
     pub fn fdh_decompressor_ignore_adler32(d: *mut fdh_decompressor);
     pub fn fdh_decompressor_is_done(d: *const fdh_decompressor) -> c_int;
+    /// Introspection (not part of the reference API): decode attempts made so far.
+    pub fn fdh_decompressor_attempts(d: *const fdh_decompressor) -> u64;
     pub fn fdh_decompressor_read(d: *mut fdh_decompressor, input: *const u8, input_len: usize, output: *mut u8,
                                  output_len: usize, output_position: usize, consumed: *mut usize,
                                  produced: *mut usize, stream_status: *mut u32) -> c_int;
