@@ -24,6 +24,7 @@
 #include "inflate_lanes.h"
 #include "inflate_segments.h"
 #include "inflate_seg2.h"
+#include "inflate_lz.h"
 
 namespace fdh {
 
@@ -79,6 +80,7 @@ struct InflateBatchArgs {
     uint32_t* list;  // nullable: compacted ids of the PENDING streams ([0] = count, [2] / [3] = hand-out counters of
                      // the fast / the 12-bit general kernel, [4..] = ids)
     uint32_t* span_pool;   // nullable: kSpanSlots busy flags, then kSpanSlots match lists (span decoder scratch)
+    uint32_t* lz_counter;  // hand-out counter of the LZ-window kernel (zeroed by the launcher)
 };
 constexpr uint32_t kSpanSlots = 2048;  // > workgroups of the general kernel resident on one device (256 CUs x 5)
 
@@ -224,6 +226,100 @@ __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_genera
         return;
     }
     general_fast_one(a, lds, blockIdx.x);
+}
+
+// LZ-window kernel (inflate_lz.h): any stream of Huffman blocks, the history in LDS.  One wavefront =
+// one workgroup = one stream at a time, four per CU.  Returns true when the stream is finished (Ok).
+__device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, const uint64_t sid) {
+    const int lane = threadIdx.x;
+    if (sid >= a.n) return false;
+    if (a.only_pending && a.status[sid] != kPending) return false;
+    const StreamArgs s = stream_args(a, sid);
+    if (s.in_len < 8 || s.in_len >= (1ull << 27) || s.cap >= (1u << 30) || s.cap < 16) return false;  // 32-bit bit positions; far sources are read 16 bytes at a time
+    const uint32_t in_bits = (uint32_t)s.in_len * 8;
+    InflaterT<kLzLitBits, false> inf(L.tables, *reinterpret_cast<WaveIo*>(&L.u.hdr), &L.u.hdr.hs, lane);
+    inf.init(s);
+    if (inf.parse_zlib_header() != RC_OK) return false;
+    LzOut o;
+    o.out_al = inf.out_al;
+    o.gmis = inf.gmis;
+    o.O = 0;
+    o.o_ri = inf.gmis;
+    o.flushed = 0;
+    o.adler_a = 1;
+    o.adler_b = 0;
+    uint32_t bitpos = 16;
+#ifdef FDH_LZ_DEBUG
+    o.tq = clock64();
+#endif
+    for (;;) {  // blocks
+        inf.refill();
+        if (inf.left < 10) return false;
+        const uint32_t type = ((uint32_t)inf.bb >> 1) & 3;
+        if (type == 0 || type == 3) return false;  // stored blocks: the kernels behind
+        const bool had_fixed = inf.fixed_built;
+        const uint32_t rc = inf.parse_block_header();
+        if (rc != RC_OK && rc != RC_EOB) return false;
+        if (rc == RC_OK && (type == 2 || !had_fixed)) {  // freshly built: the walk's entry layout, the second level
+            lz_convert_tables(L.tables, lane);
+            lz_build_sub(L, lane);
+        }
+        const bool last = inf.last_block;
+        bitpos = (uint32_t)inf.consumed_bits();
+        const LzBounds bd = lz_load_bounds(L.tables);
+        LZT(o, 0);
+        if (rc == RC_OK) {
+            uint32_t R = kLzRange;
+            for (uint32_t nspans = 0;; nspans++) {  // spans
+                if (bitpos >= in_bits || nspans > in_bits) return false;
+                const uint32_t fair = (in_bits - bitpos + kWave - 1) / kWave;
+                const uint32_t r = min(R, max(fair, 8u));
+                const uint32_t res = lz_span(L, o, bd, inf.base16, inf.mis, inf.win_bytes, s.buf_lo, s.buf_hi, in_bits, s.cap, bitpos, r, lane);
+                if (res == LZ_BAIL) return false;
+                if (res == LZ_SHRINK) {
+                    if (r <= 8) return false;
+                    R = max(8u, r / 4);
+                    continue;
+                }
+                if (res == LZ_EOB) break;
+            }
+        }
+        // back to the wave-serial reader (its window shares LDS with the span's stage: reload)
+        if (bitpos > in_bits) return false;
+        inf.left = in_bits - bitpos;
+        inf.loaded = 0x7FFFFFF0u;
+        inf.seek(bitpos);
+        if (last) break;
+    }
+    uint32_t stored = 0;
+    if (inf.read_trailer(stored) != RC_OK) return false;
+    lz_flush(L, o, true, lane);
+    const uint32_t adler = (o.adler_b << 16) | o.adler_a;
+    if (!(a.flags & 1u) && stored != adler) return false;  // WrongChecksum is the exact kernels' verdict
+    if (lane == 0) {
+        a.status[sid] = ST_OK;
+        a.out_len[sid] = o.O;
+        if (a.adler) a.adler[sid] = adler;
+    }
+    LZT(o, 8);
+#ifdef FDH_LZ_DEBUG
+    if (lane == 0) {
+        for (int k = 0; k < 32; k++)
+            if (o.t[k]) atomicAdd(&g_lzstat[k], o.t[k]);
+        atomicAdd(&g_lzstat[31], 1ull);
+    }
+#endif
+    return true;
+}
+__global__ __launch_bounds__(kWave, 2) void inflate_lz_kernel(InflateBatchArgs a) {
+    __shared__ LzLds lds;
+    const uint32_t cnt = a.list[0];
+    for (uint32_t i = blockIdx.x; i < cnt;) {
+        lz_one(a, lds, a.list[4 + i]);
+        wave_sync();
+        if (threadIdx.x == 0) i = atomicAdd(a.lz_counter, 1u) + gridDim.x;
+        i = uni(i);
+    }
 }
 
 struct CanonLds {
@@ -572,6 +668,15 @@ extern "C" int fdh_debug_s2(uint32_t* host, uint32_t sid) {  // returns the reco
 }
 #endif
 
+#ifdef FDH_LZ_DEBUG
+extern "C" int fdh_debug_read_lzstat(unsigned long long* host, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_lzstat), 32 * 8);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_lzstat), z, 32 * 8); }
+    return 0;
+}
+#endif
+
 #ifdef FDH_S2_DEBUG
 extern "C" int fdh_debug_s2time(uint32_t* host) {
     hipDeviceSynchronize();
@@ -611,7 +716,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr};
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr};
     if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
         int ordinal = 0;
         if (hipGetDevice(&ordinal) == hipSuccess && ordinal >= 0 && ordinal < 64) {
@@ -716,6 +821,16 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             // the general kernels walk the same list (what the canon kernel finished is no longer PENDING):
             // a grid-stride loop, so a batch that is all canonical costs two near-empty launches
             const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 4096);  // persistent workgroups (16 per CU at most)
+            if (e == hipSuccess && !(flags & 0x1000u)) {  // the LZ-window kernel: persistent wavefronts, FDH_LZ_WAVES_PER_CU per CU
+                a.lz_counter = list + (n + 4) + 2;  // (a spare word of stream_order_kernel's counters, zeroed above)
+                const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);
+                hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, stream, a);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess && (flags & 0x2000u)) {  // debug: what the LZ-window kernel left stays PENDING
+                (void)hipFreeAsync(list, stream);
+                return 0;
+            }
             if (e == hipSuccess && !(flags & 0x200u)) {
                 hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3(gblocks), dim3(fdh::kWave), 0, stream, a);
                 e = hipGetLastError();

@@ -1,0 +1,793 @@
+// inflate_lz.h -- the LZ-window decoder: any zlib stream of Huffman blocks (dynamic or fixed, real
+// distances, several blocks), one stream per wavefront, the sliding window in LDS.
+//
+// Restates (behaviour, not code) the compressed-block loop of the reference,
+// src/decompress.rs:611-1018 (match copy :782-829), with the tables of src/huffman.rs:18-184 as
+// inflate_tables.h builds them.  tests/lz_model.py is an executable CPU model of the algorithm.
+//
+// A block's data is decoded in SPANS of 64 x R stream bits, one bit range per lane:
+//
+//   pass 1   a lane walks a guessed chain from up to kLzWarm bits in front of its range (impossible
+//            tokens slide on by one bit; Huffman codes self-synchronise: 86 % of the guesses of the bench's
+//            zlib-6 streams have merged with the real chain after 256 bits) and counts the output bytes of
+//            the table steps that START inside its range.
+//   check    a lane's first step at or behind its range start must be where its left neighbour's
+//            chain left the neighbour's range; by induction from lane 0 (whose start is real) every
+//            counted chain is then the real one.  Lanes that fail walk again from the neighbour's end.
+//   offsets  a wavefront prefix sum; the span takes as many lanes as fit the image (and ends with the
+//            lane that meets the end-of-block code: the lanes behind it decoded with stale tables).
+//   pass 2   decodes again: literals go to the IMAGE -- the span's output, which lives in a ring in LDS
+//            together with the history in front of it -- a match leaves a 3-byte descriptor
+//            (length - 3, distance - 1) in the first three bytes of its place and an entry in the span's match list.
+//   resolve  by match, 64 at a time in stream order (lane = match; pass 2 lists where the matches start):
+//            a match whose source bytes end in front of the batch's first match depends on nothing that is
+//            still missing -- nine in ten on the bench data -- and all of those are copied at once, a lane
+//            each; the others follow in order against a frontier.  Long or self-overlapping matches are
+//            copied by the whole wavefront.  Sources older than the ring come from the output slot in global
+//            memory (L2), one unaligned 16-B load per match, requested a batch ahead.
+//   flush    whole 16-B lines of the image to the slot, the Adler-32 folded in (as flush_ring).
+//
+// The kernel only ever reports Ok: anything else (stored blocks, errors, truncation, a slot that is
+// too small, a wrong checksum) leaves the stream PENDING for the exact kernels behind it.
+#pragma once
+#include "inflate_stream.h"
+
+namespace fdh {
+
+constexpr int kLzLitBits = 10;
+constexpr uint32_t kLzLitMask = (1u << kLzLitBits) - 1;
+#ifndef FDH_LZ_RING
+#define FDH_LZ_RING 8192
+#endif
+#ifndef FDH_LZ_WAVES_PER_CU
+#define FDH_LZ_WAVES_PER_CU 7
+#endif
+#ifndef FDH_LZ_RANGE
+#define FDH_LZ_RANGE 288
+#endif
+#ifndef FDH_LZ_IMG
+#define FDH_LZ_IMG 4096
+#endif
+#ifndef FDH_LZ_WARM
+#define FDH_LZ_WARM 256
+#endif
+constexpr uint32_t kLzRange = FDH_LZ_RANGE;  // stream bits per lane and span: an odd number of dwords, so the lanes' windows start in different LDS banks
+constexpr uint32_t kLzWarm = FDH_LZ_WARM;    // bits a guessed chain walks in front of its range
+constexpr uint32_t kLzImgCap = FDH_LZ_IMG;   // output bytes of one span
+constexpr uint32_t kLzRing = FDH_LZ_RING;   // history + image, a multiple of 64
+constexpr bool kLzRingPow2 = (kLzRing & (kLzRing - 1)) == 0;
+constexpr uint32_t kLzStageDw = ((64 * kLzRange + 127 + 31) / 32 + 8 + 3) & ~3u;  // the span + what a walk reads beyond it + alignment
+constexpr uint32_t kLzIdxCap = kLzImgCap / 4;  // matches of one span (a match is at least three bytes; the bench's zlib-6 streams: one per 5.2)
+static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 1024, "ring = image + history");
+
+struct __attribute__((aligned(16))) LzWork {
+    uint32_t stage[kLzStageDw];    // the span's stream bytes (coalesced copy)
+    uint16_t idx[kLzIdxCap];       // where the span's matches start in the image, in stream order
+};
+constexpr uint32_t kLzSub = 512;  // second-level entries of the literal/length table (codes of 11 .. 15 bits)
+struct __attribute__((aligned(16))) LzLds {
+    TableSetT<kLzLitBits> tables;  // lit / dist re-encoded for the walk (lz_convert_tables)
+    uint32_t sub[kLzSub];          // second level of tables.lit (lz_build_sub)
+    union {
+        // block headers are parsed by the wave-serial reader (inflate_stream.h) between spans: it only ever
+        // touches WaveIo::in_ring (its first member) and the header scratch, so that is all it gets
+        struct {
+            uint32_t in_ring[kInRingDw];
+            HeaderScratch hs;
+        } hdr;
+        LzWork w;
+    } u;
+    uint8_t ring[kLzRing + 16];  // output position p lives at (p + gmis) mod kLzRing; 3 guard bytes for descriptors
+};
+static_assert((sizeof(LzLds) + 1024) * FDH_LZ_WAVES_PER_CU <= 163840, "wavefronts per CU (LDS is handed out in larger pieces than a byte: keep a margin)");
+static_assert(offsetof(WaveIo, in_ring) == 0, "the reader's window is the first member of WaveIo");
+
+__device__ __forceinline__ uint32_t lz_wrap(uint32_t i) {  // i < 2 * kLzRing
+    if (kLzRingPow2) return i & (kLzRing - 1);
+    return i >= kLzRing ? i - kLzRing : i;
+}
+__device__ __forceinline__ uint32_t lz_back(uint32_t i, uint32_t back) {  // ring index `back` (<= kLzRing) in front of i
+    if (kLzRingPow2) return (i - back) & (kLzRing - 1);
+    const int32_t r = (int32_t)i - (int32_t)back;
+    return (uint32_t)(r < 0 ? r + (int32_t)kLzRing : r);
+}
+
+#ifdef FDH_LZ_DEBUG
+__device__ unsigned long long g_lzstat[32];
+#define LZT(o, k) do { const long long tn_ = clock64(); (o).t[k] += (unsigned long long)(tn_ - (o).tq); (o).tq = tn_; } while (0)
+#define LZC(o, k, v) do { (o).t[k] += (unsigned long long)(v); } while (0)
+#else
+#define LZT(o, k) do { } while (0)
+#define LZC(o, k, v) do { } while (0)
+#endif
+
+// ---- the walk's table entries (built from the device tables of inflate_tables.h) ----
+//   literal/length, index = low 10 stream bits:
+//     literals  [4:0] bits of the step, [6:5] literals (1 / 2), [15:8] first, [23:16] second
+//     length    bit 31; [4:0] code + extra bits, [7:5] extra bits, [11:8] code bits, [24:16] length base
+//     special   bit 30; [4:0] bits, [29:28] 0 end-of-block / 1 code beyond the index (canonical walk) / 2 impossible /
+//               3 code beyond the index with a second level: [4:0] its index bits (stream bits 10 ..), [27:8] its
+//               first entry in LzLds::sub (entries there are literal / length / end-of-block entries with the full code length)
+//   distance, index = low 9 bits:
+//     [4:0] code + extra bits, [8:5] code bits, [12:9] extra bits, [31:16] base; bit 13 special ([14]: code beyond the index)
+constexpr uint32_t LZW_LEN = 1u << 31, LZW_SPECIAL = 1u << 30, LZD_SPECIAL = 1u << 13, LZD_LONG = 1u << 14;
+constexpr uint32_t LZW_TWO = LZW_SPECIAL | (3u << 28);  // (e & LZW_TWO) == LZW_TWO: second-level look-up
+
+__device__ __forceinline__ uint32_t lz_conv_lit(uint32_t e) {
+    const uint32_t nb = e & 15, k = (e >> 4) & 15;
+    if (k == K_LIT1) return nb | (1u << 5) | (e & 0xFF00u);
+    if (k == K_LIT2) return nb | (2u << 5) | (e & 0xFFFF00u);
+    if (k == K_LEN) {
+        const uint32_t ex = (e >> 8) & 31, base = e >> 16;
+        return LZW_LEN | (nb + ex) | (ex << 5) | (nb << 8) | (base << 16);
+    }
+    if (k == K_EOB) return LZW_SPECIAL | nb;
+    if (k == K_LONG) return LZW_SPECIAL | (1u << 28);
+    return LZW_SPECIAL | (2u << 28);
+}
+__device__ __forceinline__ uint32_t lz_conv_dist(uint32_t de) {
+    const uint32_t k = (de >> 4) & 15;
+    if (k == D_DIST) {
+        const uint32_t dcb = de & 15, dex = (de >> 8) & 15;
+        return (dcb + dex) | (dcb << 5) | (dex << 9) | (de & 0xFFFF0000u);
+    }
+    return k == D_LONG ? (LZD_SPECIAL | LZD_LONG) : LZD_SPECIAL;
+}
+__device__ __forceinline__ void lz_convert_tables(TableSetT<kLzLitBits>& T, int lane) {
+    wave_sync();
+    // (not unrolled / vectorised: hipcc 7.2 crashes in instruction selection on the unrolled form)
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int i = lane; i < (1 << kLzLitBits); i += kWave) T.lit[i] = lz_conv_lit(T.lit[i]);
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int i = lane; i < kDistSize; i += kWave) T.dist[i] = lz_conv_dist(T.dist[i]);
+    wave_sync();
+}
+
+// Second level of the literal/length table (the reference's secondary tables, src/huffman.rs:138-181, in
+// this kernel's entry layout): every 10-bit prefix that longer codes share gets 2^(longest - 10) entries
+// of LzLds::sub.  Prefixes that do not fit keep the canonical-walk marker.
+// Call after lz_convert_tables; CodeBook / sorted symbols as build_table left them.
+__device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
+    TableSetT<kLzLitBits>& T = L.tables;
+    const CodeBook& cb = T.lit_cb;
+    uint32_t nsyms = 0, offs[5], first[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        offs[i] = uni(cb.offs[11 + i]);
+        first[i] = uni(cb.first[11 + i]);
+    }
+    nsyms = offs[4] + uni(cb.hist[15]);
+    if (nsyms == offs[0]) return;  // no code beyond the index
+    constexpr uint32_t kWalk = LZW_SPECIAL | (1u << 28);  // what lz_convert_tables left in the shared prefixes
+    auto code_of = [&](uint32_t j, uint32_t& l, uint32_t& rev) __attribute__((always_inline)) {
+        const uint32_t li = (j >= offs[1] ? 1u : 0u) + (j >= offs[2] ? 1u : 0u) + (j >= offs[3] ? 1u : 0u) + (j >= offs[4] ? 1u : 0u);
+        const uint32_t o = li == 0 ? offs[0] : li == 1 ? offs[1] : li == 2 ? offs[2] : li == 3 ? offs[3] : offs[4];
+        const uint32_t f = li == 0 ? first[0] : li == 1 ? first[1] : li == 2 ? first[2] : li == 3 ? first[3] : first[4];
+        l = 11 + li;
+        rev = __brev(f + (j - o)) >> (32 - l);
+    };
+    // the longest code of every prefix, kept in the prefix's own entry: marker | length
+    for (uint32_t j = offs[0] + (uint32_t)lane; j < nsyms; j += kWave) {
+        uint32_t l, rev;
+        code_of(j, l, rev);
+        atomicMax(&T.lit[rev & kLzLitMask], kWalk | l);
+    }
+    wave_sync();
+    {   // allocation: lane i owns the prefixes 16 i .. 16 i + 15
+        uint32_t sz[16], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t e = T.lit[16 * lane + i];
+            const uint32_t m = (e & 0xFFFFFFE0u) == kWalk ? (e & 31) : 0u;
+            sz[i] = m ? 1u << (m - kLzLitBits) : 0u;
+            tot += sz[i];
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, kWave);
+            if (lane >= d) incl += y;
+        }
+        uint32_t off = incl - tot;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (sz[i]) {
+                const uint32_t m = T.lit[16 * lane + i] & 31;
+                T.lit[16 * lane + i] = off + sz[i] <= kLzSub ? (LZW_TWO | (off << 8) | (m - kLzLitBits)) : kWalk;
+                off += sz[i];
+            }
+        }
+    }
+    wave_sync();
+    for (uint32_t j = offs[0] + (uint32_t)lane; j < nsyms; j += kWave) {
+        uint32_t l, rev;
+        code_of(j, l, rev);
+        const uint32_t t = T.lit[rev & kLzLitMask];
+        if ((t & LZW_TWO) != LZW_TWO) continue;  // did not fit: the canonical walk stays
+        const uint32_t longest = kLzLitBits + (t & 31), off = (t >> 8) & 0xFFFFF;
+        const uint32_t e = lz_conv_lit(LitlenTraitsT<kLzLitBits>::entry(T.lit_sorted[j], l));
+        const uint32_t step = 1u << (l - kLzLitBits), n = 1u << (longest - l);
+        uint32_t at = off + (rev >> kLzLitBits);
+        for (uint32_t i = 0; i < n; i++, at += step) L.sub[at] = e;
+    }
+    wave_sync();
+}
+
+struct LzTok {
+    uint32_t kind;  // 0 literal(s), 1 match, 2 end-of-block, 3 impossible
+    uint32_t bits, n, v;  // v: literals b0 | b1 << 8 / match: length | dist << 16
+};
+
+// Bounds of the canonical codes beyond the primary tables (CodeBook::run after build_table: the
+// left-justified 16-bit bound of the codes of length <= l), uniform per block: kept in scalar registers.
+struct LzBounds {
+    uint32_t lit[5];   // lengths 11 .. 15
+    uint32_t dist[6];  // lengths 10 .. 15
+};
+__device__ __forceinline__ LzBounds lz_load_bounds(const TableSetT<kLzLitBits>& T) {
+    LzBounds b;
+#pragma unroll
+    for (int i = 0; i < 5; i++) b.lit[i] = uni(T.lit_cb.run[11 + i]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) b.dist[i] = uni(T.dist_cb.run[10 + i]);
+    return b;
+}
+
+// The token in front of (hi:lo), every case: codes beyond the primary tables are resolved against the
+// canonical bounds (long_walk of inflate_tables.h with the bounds in registers).
+__device__ __forceinline__ LzTok lz_token_slow(const TableSetT<kLzLitBits>& T, const uint32_t* sub, const LzBounds& bd, uint32_t lo, uint32_t hi) {
+    LzTok t;
+    t.kind = 3;
+    t.bits = t.n = t.v = 0;
+    uint32_t e = T.lit[lo & kLzLitMask];
+    if ((e & LZW_TWO) == LZW_TWO) e = sub[((e >> 8) & 0xFFFFF) + __builtin_amdgcn_ubfe(lo, kLzLitBits, e & 31)];
+    if ((e & LZW_SPECIAL) && ((e >> 28) & 3) == 1) {
+        const uint32_t r16 = __brev(lo) >> 16;
+        uint32_t len = 11;
+#pragma unroll
+        for (int i = 0; i < 4; i++) len += r16 >= bd.lit[i] ? 1u : 0u;
+        if (r16 >= bd.lit[4]) return t;
+        const uint32_t d = (r16 >> (16 - len)) - T.lit_cb.first[len];
+        const uint32_t sym = T.lit_sorted[T.lit_cb.offs[len] + d];
+        e = lz_conv_lit(LitlenTraitsT<kLzLitBits>::entry(sym, len));
+    }
+    if (e & LZW_SPECIAL) {
+        if (((e >> 28) & 3) == 0) {
+            t.kind = 2;
+            t.bits = e & 31;
+        }
+        return t;
+    }
+    if (!(e & LZW_LEN)) {
+        t.kind = 0;
+        t.bits = e & 31;
+        t.n = (e >> 5) & 3;
+        t.v = (e >> 8) & 0xFFFF;
+        return t;
+    }
+    const uint32_t tb = e & 31, ex = (e >> 5) & 7, nb = (e >> 8) & 15;
+    const uint32_t length = ((e >> 16) & 0x1FF) + __builtin_amdgcn_ubfe(lo, nb, ex);
+    const uint32_t dv = __builtin_amdgcn_alignbit(hi, lo, tb);
+    uint32_t de = T.dist[dv & (kDistSize - 1)];
+    if (de & LZD_SPECIAL) {
+        if (!(de & LZD_LONG)) return t;
+        const uint32_t r16 = __brev(dv) >> 16;
+        uint32_t len = 10;
+#pragma unroll
+        for (int i = 0; i < 5; i++) len += r16 >= bd.dist[i] ? 1u : 0u;
+        if (r16 >= bd.dist[5]) return t;
+        const uint32_t d = (r16 >> (16 - len)) - T.dist_cb.first[len];
+        const uint32_t sym = T.dist_sorted[T.dist_cb.offs[len] + d];
+        de = lz_conv_dist(DistTraits::entry(sym, len));
+        if (de & LZD_SPECIAL) return t;
+    }
+    const uint32_t dist = (de >> 16) + __builtin_amdgcn_ubfe(dv, (de >> 5) & 15, (de >> 9) & 15);
+    t.kind = 1;
+    t.bits = tb + (de & 31);
+    t.n = length;
+    t.v = length | (dist << 16);
+    return t;
+}
+
+struct LzWalk {
+    uint32_t b;     // first step at or behind the range start
+    uint32_t e;     // where the chain left the range (first step at or behind its end), or where it stopped
+    uint32_t cnt;   // output bytes of the steps that start inside the range
+    uint32_t nm;    // matches among them
+    uint32_t stop;  // 0 none, 1 end-of-block, 2 impossible token / past the end of the input
+    uint32_t stop_bits;
+};
+
+// One lane's walk from `pos` (a real step start if `real`) to the first step at or behind `end`;
+// positions are bits relative to the stage.  EMIT: pass 2 -- `q_rel` is the lane's offset in the
+// image, `mi` the index of its first match in the span's list.  `trouble` collects what must never happen on a real chain.
+//
+// The fast step is branch-free and the same for every lane: a lane in front of a special token (a code
+// beyond a primary table, end-of-block, an impossible token) simply does not advance; every fourth
+// step, or when nobody else moves, those lanes take the slow step, which knows every case.
+template <bool EMIT>
+__device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t pos, const uint32_t s, const uint32_t end, const bool real,
+                                          const bool active, const uint32_t limit, uint32_t q_rel, const uint32_t o_ri,
+                                          const uint32_t o_abs, uint32_t mi, bool& trouble, uint32_t* iters = nullptr, uint32_t* slows = nullptr) {
+    const TableSetT<kLzLitBits>& T = L.tables;
+    LzWalk w;
+    uint32_t b = 0xFFFFFFFFu, cnt = 0, nm = 0, stop = 0, stop_bits = 0;
+    bool run = active && pos < end;
+    uint32_t it = 0;
+    uint32_t dbad = 0;
+    while (__any(run)) {
+        if (++it > 8192) {  // cannot happen; never hang
+            trouble = true;
+            break;
+        }
+        bool special;
+        {
+            const uint32_t di = pos >> 5, sh = pos & 31;
+            const uint32_t d0 = L.u.w.stage[di], d1 = L.u.w.stage[di + 1], d2 = L.u.w.stage[di + 2];
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            uint32_t e = T.lit[lo & kLzLitMask];
+            if (__any((e & LZW_TWO) == LZW_TWO)) {  // a code of 11 .. 15 bits: its second-level entry
+                if ((e & LZW_TWO) == LZW_TWO) e = L.sub[((e >> 8) & 0xFFFFF) + __builtin_amdgcn_ubfe(lo, kLzLitBits, e & 31)];
+            }
+            const uint32_t tb = e & 31;
+            const bool is_len = (int32_t)e < 0;
+            const uint32_t length = ((e >> 16) & 0x1FF) + __builtin_amdgcn_ubfe(lo, (e >> 8) & 15, (e >> 5) & 7);
+            const uint32_t dv = __builtin_amdgcn_alignbit(hi, lo, tb);
+            const uint32_t de = T.dist[dv & (kDistSize - 1)];
+            special = (e & LZW_SPECIAL) != 0 || (is_len && (de & LZD_SPECIAL) != 0);
+            const uint32_t bits = tb + (is_len ? (de & 31) : 0u);
+            const uint32_t inc = is_len ? length : ((e >> 5) & 3);
+            const bool go = run && !special;
+            const bool started = pos >= s;
+            b = min(b, (run && started) ? pos : 0xFFFFFFFFu);
+            if (EMIT) {
+                const uint32_t qi = lz_wrap(o_ri + q_rel);
+                if (go && !is_len) {
+                    L.ring[qi] = (uint8_t)(e >> 8);
+                    if (inc == 2) L.ring[lz_wrap(qi + 1)] = (uint8_t)(e >> 16);
+                }
+                if (go && is_len) {
+                    const uint32_t dist = (de >> 16) + __builtin_amdgcn_ubfe(dv, (de >> 5) & 15, (de >> 9) & 15);
+                    dbad |= dist > o_abs + q_rel ? 1u : 0u;  // src/decompress.rs:782: the exact kernels report it
+                    const uint32_t d = (length - 3) | ((dist - 1) << 8);
+                    L.ring[qi] = (uint8_t)d;  // (past the ring's end: the guard bytes)
+                    L.ring[qi + 1] = (uint8_t)(d >> 8);
+                    L.ring[qi + 2] = (uint8_t)(d >> 16);
+                    L.u.w.idx[min(mi, kLzIdxCap - 1)] = (uint16_t)q_rel;
+                    mi++;
+                }
+                q_rel += go ? inc : 0u;  // (pass 2 starts on its range: every step counts)
+            }
+            cnt += (go && started) ? inc : 0u;
+            nm += (go && started && is_len) ? 1u : 0u;
+            pos += go ? bits : 0u;
+            run = run && pos < end;
+        }
+        if ((it & 3) == 0 || !__any(run && !special)) {
+            const bool act = run && special;
+            if (__any(act)) {
+                const uint32_t di = pos >> 5, sh = pos & 31;
+                const uint32_t d0 = L.u.w.stage[di], d1 = L.u.w.stage[di + 1], d2 = L.u.w.stage[di + 2];
+                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+                const LzTok tk = lz_token_slow(T, L.sub, bd, lo, hi);
+                if (slows) *slows += 1;
+                const bool started = pos >= s;
+                if (act) {
+                    if (tk.kind >= 2) {
+                        if (!started && !real) {
+                            pos += 1;  // a guessed chain in front of its range: slide on
+                        } else {
+                            stop = tk.kind == 2 ? 1u : 2u;
+                            stop_bits = tk.bits;
+                            run = false;
+                        }
+                    } else {
+                        if (started) {
+                            cnt += tk.n;
+                            if (EMIT) {
+                                const uint32_t qi = lz_wrap(o_ri + q_rel);
+                                if (tk.kind == 0) {
+                                    L.ring[qi] = (uint8_t)tk.v;
+                                    if (tk.n == 2) L.ring[lz_wrap(qi + 1)] = (uint8_t)(tk.v >> 8);
+                                } else {
+                                    const uint32_t length = tk.v & 0xFFFF, dist = tk.v >> 16;
+                                    dbad |= dist > o_abs + q_rel ? 1u : 0u;
+                                    const uint32_t d = (length - 3) | ((dist - 1) << 8);
+                                    L.ring[qi] = (uint8_t)d;
+                                    L.ring[qi + 1] = (uint8_t)(d >> 8);
+                                    L.ring[qi + 2] = (uint8_t)(d >> 16);
+                                    L.u.w.idx[min(mi, kLzIdxCap - 1)] = (uint16_t)q_rel;
+                                    mi++;
+                                }
+                                q_rel += tk.n;
+                            }
+                            nm += tk.kind == 1 ? 1u : 0u;
+                        }
+                        pos += tk.bits;
+                        run = pos < end;
+                    }
+                }
+            }
+        }
+    }
+    if (dbad) trouble = true;
+    if (pos > limit && stop == 0 && active) stop = 2;  // ran past the end of the input (zeros are staged there)
+    w.b = b == 0xFFFFFFFFu ? pos : b;
+    w.e = pos;
+    w.cnt = cnt;
+    w.nm = nm;
+    w.stop = stop;
+    w.stop_bits = stop_bits;
+    if (iters) *iters += it;
+    return w;
+}
+
+// 16 stream bytes at window offset `w0` (bytes from base16); zero beyond the stream, careful at the
+// ends of the packed batch (as Inflater::load_chunk).
+__device__ __forceinline__ uint4 lz_load16(const uint8_t* base16, uint64_t w0, uint64_t win_bytes, const uint8_t* buf_lo,
+                                           const uint8_t* buf_hi) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (w0 < win_bytes) {
+        const uint8_t* p = base16 + w0;
+        if (p >= buf_lo && p + 16 <= buf_hi) {
+            v = *reinterpret_cast<const uint4*>(p);
+        } else {
+            uint64_t lo = 0, hi = 0;
+            for (int j = 0; j < 8; j++) {
+                if (p + j >= buf_lo && p + j < buf_hi) lo |= (uint64_t)p[j] << (j * 8);
+                if (p + 8 + j >= buf_lo && p + 8 + j < buf_hi) hi |= (uint64_t)p[8 + j] << (j * 8);
+            }
+            v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
+        const uint64_t rem = win_bytes - w0;
+        if (rem < 16) {
+            const uint32_t r = (uint32_t)rem;
+            v.x = r >= 4 ? v.x : (r == 0 ? 0 : v.x & ((1u << (r * 8)) - 1));
+            v.y = r >= 8 ? v.y : (r <= 4 ? 0 : v.y & ((1u << ((r - 4) * 8)) - 1));
+            v.z = r >= 12 ? v.z : (r <= 8 ? 0 : v.z & ((1u << ((r - 8) * 8)) - 1));
+            v.w = r <= 12 ? 0 : v.w & ((1u << ((r - 12) * 8)) - 1);
+        }
+    }
+    return v;
+}
+
+struct LzOut {
+    uint8_t* out_al;  // slot - gmis (16-B aligned)
+    uint32_t gmis;
+    uint32_t O;       // output bytes decoded so far = start of the next image
+    uint32_t o_ri;    // ring index of position O
+    uint32_t flushed; // output bytes stored to the slot and folded into the checksum
+    uint32_t adler_a, adler_b;
+#ifdef FDH_LZ_DEBUG
+    unsigned long long t[32] = {};
+    long long tq = 0;
+#endif
+};
+
+// Stores [flushed, O) to the slot -- whole 16-B lines unless `final` -- and folds the bytes into the
+// Adler-32 (as flush_ring: order-independent per-line sums, weights from the line's place in its block).
+__device__ __forceinline__ void lz_flush(LzLds& L, LzOut& o, const bool final, const int lane) {
+    wave_sync();
+    const uint32_t q_lo = o.flushed + o.gmis;
+    uint32_t q_hi = o.O + o.gmis;
+    if (!final) q_hi &= ~15u;
+    if (q_hi <= q_lo) return;
+    const uint32_t it0 = q_lo & ~15u;
+    // ring index of q-space position it0 (q = position + gmis; ring index = q mod kLzRing)
+    uint32_t ri = lz_back(o.o_ri, o.O + o.gmis - it0);  // (the distance is < kLzRing: an image + 15)
+    for (uint32_t it = it0; it < q_hi; it += kWave * 16) {
+        const uint32_t lq = it + (uint32_t)lane * 16;
+        const uint32_t lri = lz_wrap(ri + (uint32_t)lane * 16);
+        const uint32_t blk_hi = min(q_hi, it + kWave * 16), blk_lo = max(q_lo, it);
+        uint32_t s = 0, t = 0;
+        if (lq < blk_hi && lq + 16 > blk_lo) {
+            const uint32_t lo = (blk_lo > lq) ? blk_lo - lq : 0, hi = (blk_hi < lq + 16) ? blk_hi - lq : 16;
+            const uint32_t W = blk_hi - lq;  // weight of byte j is W - j
+            const uint4 v = *reinterpret_cast<const uint4*>(&L.ring[lri]);
+            if (lo == 0 && hi == 16) {
+                *reinterpret_cast<uint4*>(o.out_al + lq) = v;
+                s = bytesum4(v.x) + bytesum4(v.y) + bytesum4(v.z) + bytesum4(v.w);
+                uint32_t u = bytedot4(v.x, 0x03020100u, 0);
+                u = bytedot4(v.y, 0x07060504u, u);
+                u = bytedot4(v.z, 0x0b0a0908u, u);
+                u = bytedot4(v.w, 0x0f0e0d0cu, u);
+                t = W * s - u;
+            } else {
+                for (uint32_t j = lo; j < hi; j++) {
+                    const uint32_t word = j < 4 ? v.x : (j < 8 ? v.y : (j < 12 ? v.z : v.w));
+                    const uint32_t b = (word >> (8 * (j & 3))) & 0xFFu;
+                    o.out_al[lq + j] = (uint8_t)b;
+                    s += b;
+                    t += (W - j) * b;
+                }
+            }
+        }
+        const uint32_t S = wave_sum_u32(s), Tt = wave_sum_u32(t);
+        const uint32_t Lb = blk_hi - blk_lo;
+        o.adler_b = (uint32_t)(((uint64_t)o.adler_b + (uint64_t)Lb * o.adler_a + Tt) % kAdlerMod);
+        o.adler_a = (o.adler_a + S) % kAdlerMod;
+        ri = lz_wrap(ri + kWave * 16);
+    }
+    o.flushed = q_hi - o.gmis;
+    wave_sync();
+}
+
+// ---- resolution of the image's matches: one match per lane, 64 at a time in stream order ----
+struct LzBatch {
+    uint32_t qi0;    // ring index of the match's first byte
+    uint32_t sidx0;  // ring index of its first source byte
+    uint32_t pos;    // its place in the image
+    uint32_t len;    // 0: no match in this lane
+    uint32_t send;   // where its source bytes end, relative to the image (wraps below zero for history)
+    uint32_t dist;
+    uint32_t sbase;  // LDS byte address of the first source byte: in the ring, or in the far buffer
+    bool simple;     // at most 16 bytes, no overlap with itself, neither end wraps around the ring
+    bool far;        // simple, and every source byte is older than the ring
+};
+// 16 bytes per lane from the slot, for sources older than the ring: requested when a batch is planned,
+// parked in LDS (the stage is idle while matches are resolved) at the end of the iteration that planned it.
+struct LzFar {
+    uint32_t f0, f1, f2, f3;
+};
+
+// What does not depend on resolved bytes: the matches of batch `mb`, their descriptors, the request for
+// sources older than the ring (one unaligned 16-B load per match: what lies behind a match's source is
+// older output of this stream, i.e. readable, as long as the slot is at least 16 bytes long).
+__device__ __forceinline__ void lz_batch_plan(LzLds& L, LzBatch& B, LzFar& Fr, const uint32_t mb, const uint32_t nmatch, const uint32_t O,
+                                              const uint32_t o_ri, const int32_t ring_lo, const uint8_t* gout, const int lane) {
+    const uint32_t m = mb + (uint32_t)lane;
+    const bool valid = m < nmatch;
+    const uint32_t pos = valid ? (uint32_t)L.u.w.idx[min(m, kLzIdxCap - 1)] : 0u;
+    const uint32_t qi0 = lz_wrap(o_ri + pos);
+    const uint32_t dsc = (uint32_t)L.ring[qi0] | ((uint32_t)L.ring[qi0 + 1] << 8) | ((uint32_t)L.ring[qi0 + 2] << 16);
+    const uint32_t len = (dsc & 0xFF) + 3, dist = (dsc >> 8) + 1;
+    const uint32_t sidx0 = lz_back(qi0, dist);
+    B.qi0 = qi0;
+    B.sidx0 = sidx0;
+    B.pos = pos;
+    B.len = valid ? len : 0u;
+    B.dist = dist;
+    B.send = pos - dist + min(len, dist);
+    const int32_t src = (int32_t)(O + pos - dist);  // >= 0 (pass 2 checked it)
+    const bool small = valid && len <= 16 && dist >= len && qi0 + 16 <= kLzRing && sidx0 + 16 <= kLzRing;
+    const bool far = small && src + (int32_t)len <= ring_lo;
+    B.far = far;
+    B.simple = small && (far || src >= ring_lo);
+    const uint32_t ring_at = (uint32_t)(reinterpret_cast<uintptr_t>(&L.ring[0]) & 0xFFFFu);
+    const uint32_t far_at = (uint32_t)(reinterpret_cast<uintptr_t>(&L.u.w.stage[0]) & 0xFFFFu);
+    B.sbase = far ? far_at + 16u * (uint32_t)lane : ring_at + sidx0;
+    // (always issued, so that the number of loads in flight is known: a lane without a far source reads the slot's start)
+    const uint32_t* gp = reinterpret_cast<const uint32_t*>(gout + (far ? (uint32_t)src : 0u));
+    Fr.f0 = __hip_atomic_load(gp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Fr.f1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Fr.f2 = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Fr.f3 = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The whole wavefront copies one match (any length, any distance, any place in the ring): byte k is
+// out[start - dist + k mod dist]; source bytes older than the ring come from the slot.
+__device__ __forceinline__ void lz_coop_copy(LzLds& L, const uint32_t qi0, const uint32_t len, const uint32_t dist, const uint32_t src0,
+                                             const int32_t ring_lo, const uint8_t* gout, const int lane) {
+    const float inv = 1.0f / (float)dist;
+    bool waited = false;
+    for (uint32_t k0 = 0; k0 < len; k0 += kWave) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        uint32_t r = k;
+        if (dist < len) {  // k mod dist for k < 258 (the quotient estimate is off by at most one)
+            const uint32_t qq = (uint32_t)((float)k * inv);
+            r = k - qq * dist;
+            r = (int32_t)r < 0 ? r + dist : r;
+            r = r >= dist ? r - dist : r;
+        }
+        if (k < len) {
+            const int32_t sp = (int32_t)(src0 + r);
+            uint32_t v;
+            if (sp < ring_lo) {
+                if (!waited) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    waited = true;
+                }
+                v = __hip_atomic_load(gout + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                uint32_t si = qi0 + kLzRing - dist + r;  // ring index of the source byte
+                si = si >= kLzRing ? si - kLzRing : si;
+                si = si >= kLzRing ? si - kLzRing : si;
+                v = L.ring[si];
+            }
+            uint32_t qi = qi0 + k;
+            qi = qi >= kLzRing ? qi - kLzRing : qi;
+            L.ring[qi] = (uint8_t)v;
+        }
+        wave_sync();
+    }
+}
+
+// Copies the matches of one planned batch.  Matches whose source bytes end in front of the batch's first
+// match depend on nothing that is still missing (literals are in place, the batches before are done):
+// all of them at once, a lane each.  The others in stream order, against a frontier: a match is ready
+// when its source bytes end at or below the start of the first match not copied yet.
+__device__ __forceinline__ void lz_batch_fill(LzLds& L, const LzBatch& B, const uint32_t O, const int32_t ring_lo,
+                                              const uint8_t* gout, const int lane, uint32_t& rounds) {
+    const uint32_t F = __builtin_amdgcn_readfirstlane(B.pos);  // (lane 0 always holds a match)
+    const uint8_t __attribute__((address_space(3)))* const sp = (const uint8_t __attribute__((address_space(3)))*)(uintptr_t)B.sbase;
+    auto copy = [&](const bool go) __attribute__((always_inline)) {
+        // go: simple matches only.  Reads first, then writes (a round's sources are never its destinations);
+        // four bytes at a time, as far as the longest match of the round needs
+        uint32_t longest = go ? B.len : 0u;
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, x, kWave));
+        longest = uni(longest);
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+            if ((uint32_t)k0 >= longest) break;
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = sp[k0 + k];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (go && (uint32_t)(k0 + k) < B.len) L.ring[B.qi0 + k0 + k] = (uint8_t)v[k];
+        }
+    };
+    const bool indep = B.simple && (B.far || (int32_t)B.send <= (int32_t)F);
+    copy(indep);
+    uint64_t todo = __ballot(B.len != 0 && !indep);
+    while (todo) {
+        rounds++;
+        wave_sync();
+        const int f = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t fpos = __builtin_amdgcn_readlane(B.pos, f);
+        if (!__builtin_amdgcn_readlane(B.simple ? 1u : 0u, f)) {
+            const uint32_t flen = __builtin_amdgcn_readlane(B.len, f), fdist = __builtin_amdgcn_readlane(B.dist, f);
+            lz_coop_copy(L, __builtin_amdgcn_readlane(B.qi0, f), flen, fdist, O + fpos - fdist, ring_lo, gout, lane);
+            todo &= todo - 1;
+            continue;
+        }
+        const bool waiting = (todo >> lane) & 1;
+        const bool ready = waiting && B.simple && (lane == f || (int32_t)B.send <= (int32_t)fpos);
+        copy(ready);
+        todo &= ~__ballot(ready);
+    }
+    wave_sync();
+}
+
+enum : uint32_t { LZ_MORE = 0, LZ_EOB = 1, LZ_BAIL = 2, LZ_SHRINK = 3 };
+
+// One span of the current block from stream bit `bitpos`.  LZ_MORE / LZ_EOB: `bitpos` advanced, the
+// image resolved, flushed and part of the history.  LZ_SHRINK: not even lane 0 fits the image with
+// this R.  LZ_BAIL: this stream is for the exact kernels.
+__device__ __forceinline__ uint32_t lz_span(LzLds& L, LzOut& o, const LzBounds& bd, const uint8_t* base16, const uint32_t mis,
+                                            const uint64_t win_bytes, const uint8_t* buf_lo, const uint8_t* buf_hi,
+                                            const uint32_t in_bits, const uint32_t cap, uint32_t& bitpos, const uint32_t R,
+                                            const int lane) {
+    // ---- stage the span's bytes ----
+    const uint32_t wbit = bitpos + mis * 8;       // window bit of the span's first bit
+    const uint32_t c0 = (wbit >> 5) & ~3u;        // first staged dword, 16-B aligned
+    const uint32_t rel0 = wbit - c0 * 32;         // the span's first bit, relative to the stage
+    const uint32_t limit = in_bits + mis * 8 - c0 * 32;
+    const uint32_t need_dw = min((uint32_t)kLzStageDw, ((rel0 + kWave * R + 31) / 32 + 8 + 3) & ~3u);
+    wave_sync();
+    for (uint32_t i = (uint32_t)lane * 4; i < need_dw; i += kWave * 4) {
+        const uint4 v = lz_load16(base16, ((uint64_t)c0 + i) * 4, win_bytes, buf_lo, buf_hi);
+        *reinterpret_cast<uint4*>(&L.u.w.stage[i]) = v;
+    }
+    wave_sync();
+    LZT(o, 1);
+    // ---- pass 1 ----
+    const uint32_t s = rel0 + (uint32_t)lane * R, end = s + R;
+    const bool live = s < limit;
+    const uint32_t ws = (s - rel0 > kLzWarm) ? s - kLzWarm : rel0;
+    bool trouble = false;
+    uint32_t iters = 0, slows = 0;
+    LzWalk w = lz_walk<false>(L, bd, ws, s, end, ws == rel0, live, limit, 0, 0, 0, 0, trouble, &iters, &slows);
+    if (!live) {
+        w.b = w.e = s;
+        w.cnt = w.nm = 0;
+        w.stop = 2;
+    }
+    LZT(o, 2);
+    // ---- check, fix-up rounds ----
+    uint32_t start = w.b;
+    int first_stop = kWave;
+    bool converged = false;
+    for (int round = 0; round <= kWave; round++) {
+        const uint32_t prev_e = __shfl_up(w.e, 1, kWave), prev_stop = __shfl_up(w.stop, 1, kWave);
+        const bool ok = lane == 0 || (prev_stop == 0 && start == prev_e);
+        const uint64_t bad_mask = __ballot(!ok);
+        const int first_bad = bad_mask ? __ffsll((unsigned long long)bad_mask) - 1 : kWave;
+        const uint64_t stop_mask = __ballot(w.stop != 0) & (first_bad < kWave ? lanemask_lt(first_bad) : ~0ull);
+        first_stop = stop_mask ? __ffsll((unsigned long long)stop_mask) - 1 : kWave;
+        if (first_stop < kWave || first_bad == kWave) {
+            converged = true;
+            break;
+        }
+        const bool redo = !ok && prev_stop == 0;
+        LZC(o, 10, 1);
+        const bool empty = redo && prev_e >= end;  // the neighbour's last step covers this whole range
+        const LzWalk w2 = lz_walk<false>(L, bd, prev_e, s, end, true, redo && !empty, limit, 0, 0, 0, 0, trouble, &iters, &slows);
+        if (redo) {
+            start = prev_e;
+            if (empty) {
+                w.b = w.e = prev_e;
+                w.cnt = w.nm = 0;
+                w.stop = 0;
+                w.stop_bits = 0;
+            } else {
+                w = w2;
+                w.b = prev_e;
+            }
+        }
+    }
+    LZT(o, 3);
+    LZC(o, 9, 1);
+    LZC(o, 21, iters);
+    LZC(o, 23, slows);
+    if (!converged || __any(trouble)) return LZ_BAIL;
+    const int nvalid = first_stop < kWave ? first_stop + 1 : kWave;
+    if (first_stop < kWave && __builtin_amdgcn_readlane(w.stop, first_stop) == 2) return LZ_BAIL;  // a bad token on the real chain
+    // ---- offsets (bytes in the low 22 bits, matches above: a lane's range holds < 2^20 bytes, < 2^9 matches) ----
+    const uint32_t cnt = lane < nvalid ? w.cnt : 0, nm = lane < nvalid ? w.nm : 0;
+    uint64_t incl64 = (uint64_t)cnt | ((uint64_t)nm << 32);
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint64_t y = __shfl_up(incl64, d, kWave);
+        if (lane >= d) incl64 += y;
+    }
+    const uint32_t incl = (uint32_t)incl64, incl_m = (uint32_t)(incl64 >> 32);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+    if (total > cap - o.O) return LZ_BAIL;  // OutputTooLarge is the exact kernels' business
+    const int nuse = __popcll(__ballot(lane < nvalid && incl <= kLzImgCap && incl_m <= kLzIdxCap));
+    if (nuse == 0) return LZ_SHRINK;
+    const uint32_t N = __builtin_amdgcn_readlane(incl, nuse - 1), nmatch = __builtin_amdgcn_readlane(incl_m, nuse - 1);
+    // ---- pass 2 ----
+    wave_sync();
+    LZT(o, 4);
+    const bool mine = lane < nuse;
+    {
+        uint32_t it2 = 0, sl2 = 0;
+        const LzWalk w2 = lz_walk<true>(L, bd, start, start, end, true, mine && start < end, limit, incl - cnt, o.o_ri, o.O, incl_m - nm, trouble, &it2, &sl2);
+        LZC(o, 20, it2);
+        LZC(o, 22, sl2);
+        const bool same = start >= end || (w2.e == w.e && w2.cnt == w.cnt && w2.nm == w.nm && w2.stop == w.stop);
+        if (__any((mine && !same) || trouble)) return LZ_BAIL;  // the passes disagree: a bug, never publish
+    }
+    wave_sync();
+    LZT(o, 5);
+    // ---- resolve the matches: 64 at a time in stream order, planned a batch ahead ----
+    if (nmatch != 0) {
+        const uint32_t O = o.O;
+        const int32_t ring_lo = (int32_t)(O + N) - (int32_t)kLzRing;  // oldest position still in the ring
+        const uint8_t* const gout = o.out_al + o.gmis;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our own flush stores: far sources are read back
+        LzBatch A, B;
+        LzFar Fr;
+        uint4* const farbuf = reinterpret_cast<uint4*>(&L.u.w.stage[0]);  // (the stage is idle until the next span)
+        lz_batch_plan(L, A, Fr, 0, nmatch, O, o.o_ri, ring_lo, gout, lane);
+        farbuf[lane] = make_uint4(Fr.f0, Fr.f1, Fr.f2, Fr.f3);
+        uint32_t rounds = 0;
+        for (uint32_t mb = 0; mb < nmatch; mb += kWave) {
+            const bool more = mb + kWave < nmatch;
+            if (more) lz_batch_plan(L, B, Fr, mb + kWave, nmatch, O, o.o_ri, ring_lo, gout, lane);
+            wave_sync();
+            lz_batch_fill(L, A, O, ring_lo, gout, lane, rounds);
+            if (more) {  // (the loads of the next batch have had the whole fill to arrive)
+                farbuf[lane] = make_uint4(Fr.f0, Fr.f1, Fr.f2, Fr.f3);
+                A = B;
+            }
+            LZC(o, 11, 1);
+        }
+        LZC(o, 12, rounds);
+    }
+    wave_sync();
+    LZT(o, 6);
+    // ---- the image becomes history; where the stream continues ----
+    o.O += N;
+    o.o_ri = lz_wrap(o.o_ri + N);
+    lz_flush(L, o, false, lane);
+    LZT(o, 7);
+    const uint32_t last_e = __builtin_amdgcn_readlane(w.e, nuse - 1), last_sb = __builtin_amdgcn_readlane(w.stop_bits, nuse - 1);
+    const bool eob = nuse == nvalid && first_stop < kWave;
+    bitpos = last_e + (eob ? last_sb : 0u) - rel0 + bitpos;
+    return eob ? LZ_EOB : LZ_MORE;
+}
+
+}  // namespace fdh

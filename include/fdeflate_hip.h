@@ -72,6 +72,8 @@ enum {
 #define FDH_FLAG_NO_FAST_GENERAL 0x200u /* tests/A-B: skip the small-table general kernel */
 #define FDH_FLAG_NO_INTERVALS   0x400u /* tests/A-B: skip the interval kernel (segment kernel first, as in round 2) */
 #define FDH_FLAG_INTERVALS_ONLY 0x800u /* debug: run only the interval kernel (what it leaves stays PENDING) */
+#define FDH_FLAG_NO_LZ          0x1000u /* tests/A-B: skip the LZ-window kernel (general streams go to the tile decoders) */
+#define FDH_FLAG_LZ_ONLY        0x2000u /* debug: nothing behind the LZ-window kernel runs (what it leaves stays PENDING) */
 #define FDH_FLAG_SPANS          0x100u /* experimental: segment-parallel "span" decoder inside the 12-bit general kernel */
 
 /*
