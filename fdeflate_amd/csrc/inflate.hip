@@ -257,12 +257,28 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
         if (inf.left < 10) return false;
         const uint32_t type = ((uint32_t)inf.bb >> 1) & 3;
         if (type == 0 || type == 3) return false;  // stored blocks: the kernels behind
-        const bool had_fixed = inf.fixed_built;
-        const uint32_t rc = inf.parse_block_header();
-        if (rc != RC_OK && rc != RC_EOB) return false;
-        if (rc == RC_OK && (type == 2 || !had_fixed)) {  // freshly built: the walk's entry layout, the second level
-            lz_convert_tables(L.tables, lane);
+        uint32_t rc;
+        if (type == 2) {  // dynamic: this kernel's own parser and table builder
+            if (inf.left < 17) return false;
+            inf.last_block = ((uint32_t)inf.bb & 1) != 0;
+            const uint32_t hlit = (((uint32_t)inf.bb >> 3) & 31) + 257, hdist = (((uint32_t)inf.bb >> 8) & 31) + 1;
+            const uint32_t hclen = (((uint32_t)inf.bb >> 13) & 15) + 4;
+            if (hlit > 286 || hdist > 30) return false;
+            inf.consume(17);
+            inf.fixed_built = false;
+            LZT(o, 0);
+            if (!lz_parse_dynamic(L, inf, hlit, hdist, hclen, lane, o)) return false;
             lz_build_sub(L, lane);
+            LZT(o, 17);
+            rc = RC_OK;
+        } else {
+            const bool had_fixed = inf.fixed_built;
+            rc = inf.parse_block_header();
+            if (rc != RC_OK && rc != RC_EOB) return false;
+            if (rc == RC_OK && !had_fixed) {  // freshly built: the walk's entry layout (fixed codes: nothing beyond the index)
+                lz_convert_tables(L.tables, lane);
+                lz_build_sub(L, lane);
+            }
         }
         const bool last = inf.last_block;
         bitpos = (uint32_t)inf.consumed_bits();

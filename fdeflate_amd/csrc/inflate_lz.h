@@ -56,7 +56,7 @@ constexpr uint32_t kLzWarm = FDH_LZ_WARM;    // bits a guessed chain walks in fr
 constexpr uint32_t kLzImgCap = FDH_LZ_IMG;   // output bytes of one span
 constexpr uint32_t kLzRing = FDH_LZ_RING;   // history + image, a multiple of 64
 constexpr bool kLzRingPow2 = (kLzRing & (kLzRing - 1)) == 0;
-constexpr uint32_t kLzStageDw = ((64 * kLzRange + 127 + 31) / 32 + 8 + 3) & ~3u;  // the span + what a walk reads beyond it + alignment
+constexpr uint32_t kLzStageDw = ((64 * kLzRange + 127 + 31) / 32 + 12 + 3) & ~3u;  // the span + what a walk reads beyond it + alignment
 constexpr uint32_t kLzIdxCap = kLzImgCap / 4;  // matches of one span (a match is at least three bytes; the bench's zlib-6 streams: one per 5.2)
 static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 1024, "ring = image + history");
 
@@ -110,6 +110,7 @@ __device__ unsigned long long g_lzstat[32];
 //               first entry in LzLds::sub (entries there are literal / length / end-of-block entries with the full code length)
 //   distance, index = low 9 bits:
 //     [4:0] code + extra bits, [8:5] code bits, [12:9] extra bits, [31:16] base; bit 13 special ([14]: code beyond the index)
+constexpr uint8_t kClclOrderHost[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // src/tables.rs:63-65
 constexpr uint32_t LZW_LEN = 1u << 31, LZW_SPECIAL = 1u << 30, LZD_SPECIAL = 1u << 13, LZD_LONG = 1u << 14;
 constexpr uint32_t LZW_TWO = LZW_SPECIAL | (3u << 28);  // (e & LZW_TWO) == LZW_TWO: second-level look-up
 
@@ -315,6 +316,7 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
     bool run = active && pos < end;
     uint32_t it = 0;
     uint32_t dbad = 0;
+
     while (__any(run)) {
         if (++it > 8192) {  // cannot happen; never hang
             trouble = true;
@@ -323,8 +325,8 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
         bool special;
         {
             const uint32_t di = pos >> 5, sh = pos & 31;
-            const uint32_t d0 = L.u.w.stage[di], d1 = L.u.w.stage[di + 1], d2 = L.u.w.stage[di + 2];
-            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            const uint32_t r0 = L.u.w.stage[di], r1 = L.u.w.stage[di + 1], r2 = L.u.w.stage[di + 2];
+            const uint32_t lo = __builtin_amdgcn_alignbit(r1, r0, sh), hi = __builtin_amdgcn_alignbit(r2, r1, sh);
             uint32_t e = T.lit[lo & kLzLitMask];
             if (__any((e & LZW_TWO) == LZW_TWO)) {  // a code of 11 .. 15 bits: its second-level entry
                 if ((e & LZW_TWO) == LZW_TWO) e = L.sub[((e >> 8) & 0xFFFFF) + __builtin_amdgcn_ubfe(lo, kLzLitBits, e & 31)];
@@ -367,8 +369,8 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
             const bool act = run && special;
             if (__any(act)) {
                 const uint32_t di = pos >> 5, sh = pos & 31;
-                const uint32_t d0 = L.u.w.stage[di], d1 = L.u.w.stage[di + 1], d2 = L.u.w.stage[di + 2];
-                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+                const uint32_t r0 = L.u.w.stage[di], r1 = L.u.w.stage[di + 1], r2 = L.u.w.stage[di + 2];
+                const uint32_t lo = __builtin_amdgcn_alignbit(r1, r0, sh), hi = __builtin_amdgcn_alignbit(r2, r1, sh);
                 const LzTok tk = lz_token_slow(T, L.sub, bd, lo, hi);
                 if (slows) *slows += 1;
                 const bool started = pos >= s;
@@ -449,6 +451,255 @@ __device__ __forceinline__ uint4 lz_load16(const uint8_t* base16, uint64_t w0, u
         }
     }
     return v;
+}
+
+// ---- dynamic block header, this kernel's own: code-length code in registers, tables filled by index ----
+// Parses a dynamic block header behind its 3 type bits + 14 count bits (hlit / hdist / hclen already read)
+// and builds the walk tables, the second level and the canonical bookkeeping.  Restates
+// src/decompress.rs:440-555 and huffman::build_table (src/huffman.rs:18-184) for the cases a valid stream
+// produces; false = anything else (an incomplete or oversubscribed code, a repeat out of range, the end of
+// the input ...): the exact kernels report it.
+//
+// Unlike the generic builder (inflate_tables.h) nothing here loops over a code's table slots: the code
+// lengths are ranked with ballots, and every table INDEX decodes itself canonically (the length of the
+// code in front of its bits is the number of left-justified bounds the bits have passed).
+template <class INF, class OUT>
+__device__ __forceinline__ bool lz_parse_dynamic(LzLds& L, INF& inf, const uint32_t hlit, const uint32_t hdist, const uint32_t hclen,
+                                                 const int lane, OUT& o) {
+    TableSetT<kLzLitBits>& T = L.tables;
+    const uint32_t lt_lo = (uint32_t)lanemask_lt(lane), lt_hi = (uint32_t)(lanemask_lt(lane) >> 32);
+    auto rank_in = [&](uint64_t m) __attribute__((always_inline)) -> uint32_t {  // lanes of m below this one
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    (void)lt_lo;
+    (void)lt_hi;
+    // ---- the header's bits: 1 KiB from the current position, lane i holding dwords i, i + 64, i + 128, i + 192 ----
+    // (a header is at most 57 + 316 x 14 bits; the chain below is a scalar loop, so the bits come out of
+    // registers with readlane -- no LDS trip, no execution-mask juggling per token)
+    const uint64_t P = inf.consumed_bits();
+    const uint32_t wbit = (uint32_t)P + inf.mis * 8, c0 = (wbit >> 5) & ~3u;
+    wave_sync();
+    *reinterpret_cast<uint4*>(&L.u.w.stage[4 * lane]) = lz_load16(inf.base16, (uint64_t)c0 * 4 + 16u * (uint32_t)lane, inf.win_bytes, inf.buf_lo, inf.buf_hi);
+    wave_sync();
+    const uint32_t hA = L.u.w.stage[lane], hB = L.u.w.stage[64 + lane], hC = L.u.w.stage[128 + lane], hD = L.u.w.stage[192 + lane];
+    wave_sync();
+    auto word = [&](uint32_t di) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t a = __builtin_amdgcn_readlane(hA, di & 63), b2 = __builtin_amdgcn_readlane(hB, di & 63);
+        const uint32_t c = __builtin_amdgcn_readlane(hC, di & 63), d = __builtin_amdgcn_readlane(hD, di & 63);
+        return di < 64 ? a : di < 128 ? b2 : di < 192 ? c : d;
+    };
+    uint32_t di = (wbit - c0 * 32) >> 5, used = 0;
+    const uint32_t sh0 = (wbit - c0 * 32) & 31;
+    uint64_t buf = (uint64_t)(word(di) >> sh0);
+    uint32_t cnt = 32 - sh0;
+    di++;
+    auto refill = [&]() __attribute__((always_inline)) {  // afterwards cnt >= 33
+        if (cnt <= 32) {
+            buf |= (uint64_t)word(di) << cnt;
+            cnt += 32;
+            di++;
+        }
+    };
+    auto consume = [&](uint32_t n) __attribute__((always_inline)) {
+        buf >>= n;
+        cnt -= n;
+        used += n;
+    };
+    // ---- the code-length code: 19 lengths of 3 bits, lane s holds the length of symbol s ----
+    uint32_t cl = 0;
+#pragma unroll
+    for (int i = 0; i < 19; i++) {
+        if ((uint32_t)i < hclen) {
+            refill();
+            const uint32_t v = (uint32_t)buf & 7;
+            consume(3);
+            cl = lane == (int)kClclOrderHost[i] ? v : cl;
+        }
+    }
+    uint32_t ccode = 0;
+    {
+        uint32_t kraft = 0, code = 0, prev = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 7; l++) {
+            const uint64_t m = __ballot(cl == l);
+            const uint32_t n = (uint32_t)__popcll(m);
+            kraft += n << (7 - l);
+            code = (code + prev) << 1;
+            prev = n;
+            ccode = cl == l ? code + rank_in(m) : ccode;
+        }
+        if (kraft != 128) return false;  // src/huffman.rs:72-75: the code-length code must be complete
+    }
+    // its 128-entry table in two registers: lane i holds entries i and i + 64 (symbol | bits << 8)
+    uint32_t t_lo = 0, t_hi = 0;
+    {
+        const uint32_t crev = cl ? __brev(ccode) >> (32 - cl) : 0u;
+        for (int sy = 0; sy < 19; sy++) {
+            const uint32_t l = __builtin_amdgcn_readlane(cl, sy), r = __builtin_amdgcn_readlane(crev, sy);
+            if (l == 0) continue;
+            const uint32_t mask = (1u << l) - 1, e = (uint32_t)sy | (l << 8);
+            t_lo = ((uint32_t)lane & mask) == r ? e : t_lo;
+            t_hi = (((uint32_t)lane + 64u) & mask) == r ? e : t_hi;
+        }
+    }
+    LZT(o, 13);
+    // ---- the literal/length + distance code lengths: one chain of bits, a scalar loop ----
+    // the length of symbol n lives in lane n mod 64 of Ln[n / 64]
+    const uint32_t total = hlit + hdist;
+    uint32_t Ln[5] = {0, 0, 0, 0, 0};
+    uint32_t nread = 0, prevlen = 0;
+    while (nread < total) {
+        refill();
+        const uint32_t idx = (uint32_t)buf & 127;
+        const uint32_t e0 = __builtin_amdgcn_readlane(t_lo, idx & 63), e1 = __builtin_amdgcn_readlane(t_hi, idx & 63);
+        const uint32_t e = idx & 64 ? e1 : e0;
+        const uint32_t sym = e & 0xFF, nb = e >> 8;
+        if (nb == 0) return false;
+        uint32_t rep = 1, value = sym, bits = nb;
+        if (sym > 15) {
+            const uint32_t extra = sym == 16 ? 2u : sym == 17 ? 3u : 7u, base_rep = sym == 18 ? 11u : 3u;
+            if (sym == 16 && nread == 0) return false;
+            value = sym == 16 ? prevlen : 0u;
+            rep = (((uint32_t)buf >> nb) & ((1u << extra) - 1)) + base_rep;
+            bits = nb + extra;
+            if (nread + rep > total) return false;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) Ln[k] = ((uint32_t)lane + 64u * k - nread) < rep ? value : Ln[k];
+        prevlen = value;
+        nread += rep;
+        consume(bits);
+    }
+    if ((uint64_t)used > inf.left) return false;  // the header runs past the end of the input
+    inf.left -= used;
+    LZT(o, 14);
+    if (__builtin_amdgcn_readlane(Ln[4], 0) == 0) return false;  // no end-of-block code (src/decompress.rs:563-566)
+
+    // ---- canonical bookkeeping of a code: lengths ranked with ballots ----
+    // sym_len(k): length of symbol lane + 64 k.  Writes sorted[], the CodeBook; returns false unless complete.
+    auto canon = [&](auto&& sym_len, const int rounds, CodeBook& cb, uint16_t* sorted, uint32_t (&bound)[16], uint32_t& nsyms,
+                     uint32_t& maxlen) __attribute__((always_inline)) -> bool {
+        uint32_t hist[16], first[16], offs[16];
+        hist[0] = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            uint32_t n = 0;
+            for (int k = 0; k < rounds; k++) n += (uint32_t)__popcll(__ballot(sym_len(k) == l));
+            hist[l] = n;
+        }
+        uint32_t kraft = 0, code = 0, off = 0;
+        nsyms = 0;
+        maxlen = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            kraft += hist[l] << (15 - l);
+            code = (code + hist[l - 1]) << 1;
+            first[l] = code;
+            offs[l] = off;
+            off += hist[l];
+            bound[l] = (code + hist[l]) << (16 - l);
+            if (hist[l]) maxlen = l;
+        }
+        nsyms = off;
+        // (lane l keeps the books the slow path and the second level read)
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            if (lane == (int)l) {
+                cb.hist[l] = hist[l];
+                cb.first[l] = first[l];
+                cb.offs[l] = offs[l];
+                cb.run[l] = bound[l];
+            }
+        }
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            uint32_t seen = 0;
+            for (int k = 0; k < rounds; k++) {
+                const uint64_t m = __ballot(sym_len(k) == l);
+                if (sym_len(k) == l) sorted[offs[l] + seen + rank_in(m)] = (uint16_t)(lane + 64 * k);
+                seen += (uint32_t)__popcll(m);
+            }
+        }
+        return kraft == (1u << 15);
+    };
+    uint32_t ll[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) ll[k] = (uint32_t)lane + 64u * k < hlit ? Ln[k] : 0u;
+    uint32_t dl;
+    {   // the distance lengths are the symbols hlit .. hlit + hdist - 1 of the chain: lane i wants symbol hlit + i
+        const uint32_t at = hlit + (uint32_t)lane, ka = hlit >> 6;  // ka = 4 (hlit >= 257): Ln[4], then (never) beyond
+        (void)ka;
+        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((at & 63) << 2), (int)Ln[4]);
+        dl = ((uint32_t)lane < hdist && (at >> 6) == 4) ? v : 0u;
+        if (hlit + hdist > 320) return false;  // cannot happen (286 + 30)
+    }
+    uint32_t lb[16], db[16], ln, lmax, dn, dmax;
+    const bool lit_ok = canon([&](int k) { return ll[k]; }, 5, T.lit_cb, T.lit_sorted, lb, ln, lmax);
+    if (!lit_ok) return false;  // src/decompress.rs:570-580
+    const bool dist_ok = canon([&](int) { return dl; }, 1, T.dist_cb, T.dist_sorted, db, dn, dmax);
+    const bool dist_none = dn == 0, dist_one = dn == 1 && dmax == 1;  // src/decompress.rs:588-589, src/huffman.rs:45-58
+    if (!dist_ok && !dist_none && !dist_one) return false;
+    wave_sync();
+    LZT(o, 15);
+
+    // ---- every table index decodes itself ----
+    auto decode = [&](const uint32_t r16, const uint32_t (&bound)[16], const int maxbits, const CodeBook& cb, const uint16_t* sorted,
+                      uint32_t& len) __attribute__((always_inline)) -> uint32_t {
+        len = 1;
+#pragma unroll
+        for (int l = 1; l < 15; l++)
+            if (l < maxbits) len += r16 >= bound[l] ? 1u : 0u;
+        if (r16 >= bound[maxbits]) {  // a code longer than the index
+            len = 0;
+            return 0;
+        }
+        return sorted[cb.offs[len] + (r16 >> (16 - len)) - cb.first[len]];
+    };
+    auto lit_entry = [&](const uint32_t sym, const uint32_t len) __attribute__((always_inline)) -> uint32_t {
+        if (sym < 256) return len | (1u << 5) | (sym << 8);
+        if (sym == 256 || sym >= 286) return LZW_SPECIAL | len;  // 286 / 287: reference src/tables.rs:100
+        const uint32_t eb = len_extra_base(sym - 257), ex = eb & 0xFF, base = eb >> 8;
+        return LZW_LEN | (len + ex) | (ex << 5) | (len << 8) | (base << 16);
+    };
+    for (int it = 0; it < (1 << kLzLitBits) / kWave; it++) {
+        const uint32_t idx = (uint32_t)lane + 64u * it;
+        uint32_t len;
+        const uint32_t sym = decode(__brev(idx) >> 16, lb, kLzLitBits, T.lit_cb, T.lit_sorted, len);
+        uint32_t e = LZW_SPECIAL | (1u << 28);  // code beyond the index: canonical walk unless the second level takes it
+        if (len) {
+            e = lit_entry(sym, len);
+            if (sym < 256 && len < (uint32_t)kLzLitBits) {  // a second literal whose code fits the index as well
+                uint32_t len2;
+                const uint32_t sym2 = decode(__brev(idx >> len) >> 16, lb, kLzLitBits, T.lit_cb, T.lit_sorted, len2);
+                if (len2 && sym2 < 256 && len + len2 <= (uint32_t)kLzLitBits) e = (len + len2) | (2u << 5) | (sym << 8) | (sym2 << 16);
+            }
+        }
+        T.lit[idx] = e;
+    }
+    for (int it = 0; it < kDistSize / kWave; it++) {
+        const uint32_t idx = (uint32_t)lane + 64u * it;
+        uint32_t e = LZD_SPECIAL;
+        if (dist_one) {  // one 1-bit code: '0' is that symbol, '1' is invalid
+            const uint32_t sym = T.dist_sorted[0];
+            if (!(idx & 1) && sym < 30) {
+                const uint32_t eb = dist_extra_base(sym), ex = eb & 0xFF;
+                e = (1 + ex) | (1u << 5) | (ex << 9) | ((eb >> 8) << 16);
+            }
+        } else if (!dist_none) {
+            uint32_t len;
+            const uint32_t sym = decode(__brev(idx) >> 16, db, kDistBits, T.dist_cb, T.dist_sorted, len);
+            if (len == 0) {
+                e = LZD_SPECIAL | LZD_LONG;
+            } else if (sym < 30) {
+                const uint32_t eb = dist_extra_base(sym), ex = eb & 0xFF;
+                e = (len + ex) | (len << 5) | (ex << 9) | ((eb >> 8) << 16);
+            }
+        }
+        T.dist[idx] = e;
+    }
+    wave_sync();
+    LZT(o, 16);
+    return true;
 }
 
 struct LzOut {
@@ -664,7 +915,7 @@ __device__ __forceinline__ uint32_t lz_span(LzLds& L, LzOut& o, const LzBounds& 
     const uint32_t c0 = (wbit >> 5) & ~3u;        // first staged dword, 16-B aligned
     const uint32_t rel0 = wbit - c0 * 32;         // the span's first bit, relative to the stage
     const uint32_t limit = in_bits + mis * 8 - c0 * 32;
-    const uint32_t need_dw = min((uint32_t)kLzStageDw, ((rel0 + kWave * R + 31) / 32 + 8 + 3) & ~3u);
+    const uint32_t need_dw = min((uint32_t)kLzStageDw, ((rel0 + kWave * R + 31) / 32 + 12 + 3) & ~3u);
     wave_sync();
     for (uint32_t i = (uint32_t)lane * 4; i < need_dw; i += kWave * 4) {
         const uint4 v = lz_load16(base16, ((uint64_t)c0 + i) * 4, win_bytes, buf_lo, buf_hi);

@@ -50,7 +50,7 @@ Lc.fdh_debug_read_lzstat(g, 1)
 g = [int(x) for x in g]
 ns = max(g[31], 1)
 names = ["header", "stage", "pass1", "fixups", "offsets", "pass2", "resolve", "flush", "trailer"]
-tot = sum(g[:9])
+tot = sum(g[:9]) + sum(g[13:18])
 print("%d streams finished by the LZ kernel, %.2f ms (instrumented), ok %d, equal %s" % (g[31], e0.elapsed_time(e1), int((st == 0).sum()), bool(torch.equal(out, raw.view(-1)))))
 print("cycles per stream: %.0f" % (tot / ns))
 for k, nm in enumerate(names):
@@ -59,3 +59,4 @@ print("  spans %.1f  fix-up rounds %.1f  match batches %.0f  ordered rounds %.0f
       (g[9] / ns, g[10] / ns, g[11] / ns, g[12] / ns, g[12] / max(g[11], 1), g[13] / ns))
 print("  walk iterations per stream: pass 1 + fix-ups %.0f (slow steps %.0f), pass 2 %.0f (slow steps %.0f)" % (g[21] / ns, g[23] / ns, g[20] / ns, g[22] / ns))
 print("  cycles per iteration: pass 1 + fix-ups %.0f, pass 2 %.0f" % ((g[2] + g[3]) / max(g[21], 1), g[5] / max(g[20], 1)))
+print("  header parts: code-length code %.0f, lengths chain %.0f, ranking %.0f, table fill %.0f, second level %.0f" % tuple(g[k] / ns for k in (13, 14, 15, 16, 17)))
