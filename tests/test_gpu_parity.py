@@ -139,9 +139,111 @@ def test_valid_streams_every_decoder_variant(harness):
             names.append("%s@%d" % (name, c))
             blobs.append(comp)
             caps.append(c)
-    # 256: span decoder (experimental); 0x400: without the interval kernel
-    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8, 256, 256 | 8, 256 | 4 | 8, 0x400, 0x400 | 8):
+    # 256: span decoder (experimental); 0x400: without the interval kernel; 0x1000: without the LZ-window
+    # kernel (the tile decoders take the general streams, as before round 4)
+    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8, 256, 256 | 8, 256 | 4 | 8, 0x400, 0x400 | 8, 0x1000, 0x1000 | 8):
         harness.assert_inflate_parity(names, blobs, caps, flags=flags)
+
+
+
+def _lz_cases():
+    """General zlib streams for the LZ-window kernel (inflate_lz.h): every zlib level and strategy on the
+    bench's buffers (noisy, half zero, all zero), short and long inputs, several blocks, text, matches that
+    repeat themselves, distances up to 32 KiB, megabyte streams of very short codes."""
+    import random
+    import zlib
+    from fdeflate_amd import synth
+    rnd = random.Random(5)
+    cases = [(n, c, r) for n, c, r in streams.valid_streams() if n != "fixed_sym286_is_eob"]
+    for lvl in (1, 4, 6, 9):
+        for sid, ln in ((0, 65536), (7, 65536), (15, 65536), (3, 20000), (4, 300), (9, 200000)):
+            raw = synth.gen_stream_np(sid, ln).tobytes()
+            cases.append(("zlib%d_s%d_%d" % (lvl, sid, ln), zlib.compress(raw, lvl), raw))
+    for strat, sname in ((zlib.Z_FIXED, "fixed"), (zlib.Z_RLE, "rle"), (zlib.Z_HUFFMAN_ONLY, "huff"), (zlib.Z_FILTERED, "filt")):
+        raw = synth.gen_stream_np(11, 50000).tobytes()
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strat)
+        cases.append(("strat_" + sname, c.compress(raw) + c.flush(), raw))
+    text = (b"the quick brown fox jumps over the lazy dog " * 400) + bytes(rnd.randrange(256) for _ in range(3000))
+    cases.append(("text", zlib.compress(text * 5, 6), text * 5))
+    raw = b"ab" * 5000 + b"xyz" * 3000 + b"q" * 70000
+    cases.append(("overlap", zlib.compress(raw, 9), raw))
+    raw = bytes(rnd.randrange(256) for _ in range(200)) + bytes(30000) + bytes(rnd.randrange(4) for _ in range(40000))
+    cases.append(("far", zlib.compress(raw, 6), raw))
+    raw = bytes(1 << 20)
+    cases.append(("zeros1M", zlib.compress(raw, 6), raw))
+    raw = bytes(rnd.randrange(3) for _ in range(1 << 20))
+    cases.append(("rand3_1M", zlib.compress(raw, 6), raw))
+    return cases
+
+
+def test_lz_window_kernel_alone(harness):
+    """FDH_FLAG_LZ_ONLY (0x2000): nothing behind the LZ-window kernel runs, so what it reports is its own.
+    It only ever reports Ok, and everything it reports is bit-exact with the oracle (bytes, length,
+    Adler-32); what it leaves (stored blocks, slots that are too small) stays PENDING.  It must take the
+    Huffman-only streams: dynamic and fixed blocks of every level / strategy."""
+    cases = _lz_cases()
+    names = [c[0] for c in cases]
+    blobs = [c[1] for c in cases]
+    for slack in (0, 100, -1):
+        caps = [max(len(c[2]) + slack, 0) for c in cases]
+        st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=0x2000)
+        assert guards_ok, "the LZ-window kernel wrote outside a slot"
+        rs, rl, ra, ro = harness.oracle_inflate(blobs, caps)
+        took = 0
+        for i, name in enumerate(names):
+            if st[i] >= 0xFFFFFFFE:  # PENDING / PENDING_SERIAL: left to the kernels that did not run
+                continue
+            assert st[i] == 0 and rs[i] == 0, (name, int(st[i]), rs[i])
+            took += 1
+            assert int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
+        if slack >= 0:
+            must = [n for n in names if n.startswith(("zlib", "strat_", "text", "overlap", "far", "zeros1M", "rand3"))]
+            left = [names[i] for i in range(len(names)) if st[i] >= 0xFFFFFFFE and names[i] in must]
+            assert not left, left
+        # (slack -1: a slot that is too small is the exact kernels' business -- whatever is reported Ok here,
+        #  e.g. an empty stream in an empty slot by the kernels in front, agreed with the oracle above)
+    # the whole pipeline on the same streams, with and without this kernel
+    caps = [len(c[2]) for c in cases]
+    harness.assert_inflate_parity(names, blobs, caps)
+    harness.assert_inflate_parity(names, blobs, caps, flags=0x1000)
+
+
+def test_zlib6_batch_at_scale_against_the_oracle(harness):
+    """SURVEY 8(d) C2 (ii) as a test: 16 384 zlib level-6 streams of the bench's buffers (two dynamic
+    blocks each, real distances up to 32 KiB, codes up to 14 bits) in one batch; status, length, Adler-32
+    and every byte of every stream against the oracle (and the raw buffers), exact slots."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    import fdeflate_amd as fd
+    from fdeflate_amd import synth
+    n, L = 16384, 65536
+    raw = synth.gen_batch_torch(0, n, L, device="cuda")
+    h = raw.cpu().numpy()
+    with ThreadPoolExecutor(16) as pool:
+        blobs = list(pool.map(lambda i: zlib.compress(h[i].tobytes(), 6), range(n), chunksize=64))
+    clen = np.array([len(b) for b in blobs], dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum((clen + 15) & ~15)
+    buf = np.zeros(int(off[-1]), dtype=np.uint8)
+    for i, b in enumerate(blobs):
+        buf[off[i]:off[i] + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    comp, c_off = torch.from_numpy(buf).cuda(), torch.from_numpy(off).cuda()
+    r_off = torch.arange(n + 1, dtype=torch.int64, device="cuda") * L
+    for flags in (0, 0x2000):  # the whole pipeline; the LZ-window kernel alone must finish all of them
+        out = torch.zeros(n * L, dtype=torch.uint8, device="cuda")
+        out_len, status, adler = fd.inflate_batch(comp, c_off, out, r_off, flags=flags)
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0, flags
+        assert bool((out_len == L).all())
+        assert torch.equal(out, raw.view(-1))
+        ad = adler.cpu().numpy().view(np.uint32)
+        ho = out.cpu().numpy()
+        for i in range(n):
+            st, dec, a = ob.decompress_bounded(blobs[i], L)
+            assert st == 0 and a == int(ad[i]), i
+            if i % 64 == 0:
+                assert dec == ho[i * L:(i + 1) * L].tobytes(), i
 
 
 def test_segment_kernel_long_canonical_streams(harness):
