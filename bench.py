@@ -48,10 +48,10 @@ def parse():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra encode / zlib-6 lines")
-    ap.add_argument("--general-streams", type=int, default=16384, help="streams given to the level-1 / RLE encoders (also lines)")
+    ap.add_argument("--general-streams", type=int, default=65536, help="streams given to the level-1 / RLE encoders (also lines)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline leg (4 legs)")
     ap.add_argument("--zlib6-streams", type=int, default=65536, help="SURVEY 8(d) C2 (ii): the same buffers as the headline")
-    ap.add_argument("--also-select", default="encode,level1,rle,png,zlib6",
+    ap.add_argument("--also-select", default="encode,level1,rle,png,zlib6,mix",
                     help="which extra lines to run (tools/profile.sh profiles them one by one)")
     ap.add_argument("--no-payload-gather", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -148,6 +148,86 @@ def encode_zlib6(raw_rows, dev):
     for i, b in enumerate(blobs):
         buf[off_h[i]:off_h[i] + len(b)] = np.frombuffer(b, dtype=np.uint8)
     return torch.from_numpy(buf).to(dev), torch.from_numpy(off_h).to(dev), torch.from_numpy(clen_h).to(dev)
+
+
+def build_mix(n, raw, uf_comp, uf_off, uf_len, dev):
+    """n streams for the mix line: a pool of distinct streams tiled in a fixed shuffled order, packed back
+    to back (any alignment is accepted), exact output slots.  -> packed input, offsets, output offsets,
+    raw lengths, expectations (python's zlib is the checker here: the inflate output of a valid stream is
+    unique)."""
+    import random
+    import zlib
+    import numpy as np
+    import torch
+    rnd = random.Random(2024)
+    pool = []   # (compressed, raw or None, Ok expected)
+    gold = os.path.join(ROOT, "tests", "golden", "vectors")
+    nref = 0
+    for name in sorted(os.listdir(os.path.join(gold, "corpus"))):
+        c = open(os.path.join(gold, "corpus", name), "rb").read()
+        pool.append((c, zlib.decompress(c), True))
+        nref += 1
+    for name in sorted(os.listdir(gold)):
+        if name.endswith(".zz"):   # (a wrong checksum, two trees without an end-of-block code: reference tests/*.zz)
+            c = open(os.path.join(gold, name), "rb").read()
+            try:
+                pool.append((c, zlib.decompress(c), True))
+            except zlib.error:
+                pool.append((c, None, False))
+            nref += 1
+    h = raw[:48].cpu().numpy()
+    for i in range(48):
+        r = h[i].tobytes()
+        kind = i % 8
+        if kind == 0:
+            c = zlib.compress(r, 0)                                   # stored blocks
+        elif kind in (1, 2, 3):
+            o = zlib.compressobj(6, zlib.DEFLATED, 15, 9, (zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY)[kind - 1])
+            c = o.compress(r) + o.flush()
+        elif kind == 4:
+            c = zlib.compress(r, 9)
+        elif kind == 5:
+            r = r[:rnd.randrange(1, 9000)]
+            c = zlib.compress(r, 6)
+        else:
+            c = zlib.compress(r, 6)
+        pool.append((c, r, True))
+    ufo = uf_off[:33].cpu().numpy()
+    ufl = uf_len[:32].cpu().numpy()
+    ufc = uf_comp[:int(ufo[32])].cpu().numpy()
+    for i in range(32):                                               # the headline's own format
+        pool.append((ufc[int(ufo[i]):int(ufo[i]) + int(ufl[i])].tobytes(), h[i].tobytes(), True))
+    good = [p for p in pool if p[2] and len(p[0]) > 64]
+    for k in range(24):                                               # damaged and truncated copies: never Ok
+        c = good[rnd.randrange(len(good))][0]
+        if k % 3 == 0:
+            pool.append((c[:rnd.randrange(8, len(c) - 4)], None, False))   # InsufficientInput
+        elif k % 3 == 1:
+            b = bytearray(c)
+            b[len(b) - 1 - rnd.randrange(4)] ^= 1 << rnd.randrange(8)      # WrongChecksum
+            pool.append((bytes(b), None, False))
+        else:
+            b = bytearray(c)
+            b[0] ^= 0x07                                                   # BadZlibHeader
+            pool.append((bytes(b), None, False))
+    order = [rnd.randrange(len(pool)) for _ in range(n)]
+    clen = np.array([len(pool[j][0]) for j in order], dtype=np.int64)
+    rlen = np.array([len(pool[j][1]) if pool[j][1] is not None else 65536 for j in order], dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum(clen)
+    buf = np.zeros(int(off[-1]) + 16, dtype=np.uint8)
+    for i, j in enumerate(order):
+        buf[off[i]:off[i] + clen[i]] = np.frombuffer(pool[j][0], dtype=np.uint8)
+    ooff = np.zeros(n + 1, dtype=np.int64)
+    ooff[1:] = np.cumsum(rlen)
+    check = [i for i in range(0, n, max(1, n // 97)) if pool[order[i]][2]]
+    exp = {"ok": torch.tensor([pool[j][2] for j in order], dtype=torch.bool, device=dev),
+           "raw": {i: pool[order[i]][1] for i in check}, "check": check,
+           "what": "%d distinct: %d reference corpus / .zz vectors, 48 zlib streams of the bench's buffers (stored, fixed, RLE, "
+                   "Huffman-only, levels 6 and 9, short ones), 32 ultra-fast streams, 24 damaged or truncated copies"
+                   % (len(pool), nref)}
+    return (torch.from_numpy(buf).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(ooff).to(dev),
+            torch.from_numpy(rlen).to(dev), exp)
 
 
 # ------------------------------------------------------------------------------------------
@@ -523,7 +603,7 @@ def main():
                              "ratio": round(float(glen.to(torch.int64).sum()) / (ng * L), 4),
                              # (host clock around a call that returns when the kernels are done)
                              "roofline": roofline(galg, gw * 1e3 / gsteps, "deflate_parse_kernel + deflate_write_kernel",
-                                                  profiled_traffic(key) if ng == args.general_streams == 16384 else None)}
+                                                  profiled_traffic(key) if ng == args.general_streams == 65536 else None)}
                     if want_cpu:
                         v, how = cpu_general_encode(native_so, raw[:64].cpu().numpy(), mode == fd.MODE_RLE, 1.5)
                         entry["cpu_port_1_thread"] = {"value": round(v, 4), "unit": "GB/s", "kind": "port",
@@ -623,12 +703,48 @@ def main():
                              "metric": "decompressed GB/s", "value": round(nz * L / (w3 / zsteps) / 1e9, 3),
                              "ms_per_step": round(w3 * 1e3 / zsteps, 4), "steps": zsteps,
                              "roofline": roofline(zalg, sum(k3) / len(k3),
-                                                  "inflate_general_fast_kernel (+ inflate_general_kernel)",
+                                                  "inflate_lz_kernel (the kernels in front pass the streams on; nothing is left for the tile decoders behind)",
                                                   profiled_traffic("zlib6") if nz == 65536 else None)})
             except KeyError:
                 pass
             except Exception as e:
                 also.append({"workload": "BASELINE config 2 (ii) (zlib-6 decode)", "error": repr(e)})
+            # BASELINE config 5 / SURVEY 8(d) C2 (iii): the mix -- the reference's corpus and .zz vectors, stored /
+            # fixed / dynamic / RLE / Huffman-only streams of the bench's buffers, ultra-fast streams, damaged and
+            # truncated copies -- tiled to n streams in one batch; Ok streams checked against the raw bytes
+            try:
+                if "mix" not in sel:
+                    raise KeyError("skipped")
+                mcomp, moff, mr_off, mraw_len, mexp = build_mix(n, raw, comp, c_off, clen, dev)
+                mout = out[:int(mr_off[-1])]
+                mst, mln, mad = status[:n], out_len[:n], adler[:n]
+
+                def m_step():
+                    fd.inflate_batch(mcomp, moff, mout, mr_off, mln, mst, mad)
+
+                m_step()
+                barrier()
+                ok = mst == 0
+                assert bool((ok == mexp["ok"]).all()), "mix: a stream's Ok / not-Ok differs from what its maker expects"
+                assert bool((mln[ok].to(torch.int64) == mraw_len[ok]).all()), "mix: length of an Ok stream"
+                for i in mexp["check"]:
+                    a0 = int(mr_off[i])
+                    assert mout[a0:a0 + int(mraw_len[i])].cpu().numpy().tobytes() == mexp["raw"][i], "mix: bytes of stream %d" % i
+                msteps = max(3, args.steps // 4)
+                w6, k6 = time_steps(m_step, msteps, 1, barrier)
+                mbytes = int(mln[ok].to(torch.int64).sum())
+                malg = int((moff[1:] - moff[:-1]).sum()) + mbytes + 24 * n
+                also.append({"workload": "BASELINE config 5 / SURVEY 8(d) C2 (iii): mix of %d streams in one batch (%s)" % (n, mexp["what"]),
+                             "metric": "decompressed GB/s", "value": round(mbytes / (w6 / msteps) / 1e9, 3),
+                             "ms_per_step": round(w6 * 1e3 / msteps, 4), "steps": msteps,
+                             "ok_streams": int(ok.sum()), "other_streams": int((~ok).sum()),
+                             "roofline": roofline(malg, sum(k6) / len(k6), "one fdh_inflate_batch call: every kernel of the pipeline",
+                                                  profiled_traffic("mix") if full else None)})
+                del mcomp, mout
+            except KeyError:
+                pass
+            except Exception as e:
+                also.append({"workload": "BASELINE config 5 (mix)", "error": repr(e)})
         if also:
             res["also"] = also
         if want_cpu:

@@ -280,7 +280,7 @@ int fdh_deflate_general_batch(const uint8_t* in, const uint64_t* in_off, uint8_t
                               uint32_t* out_len, uint64_t n, uint32_t mode, void* hip_stream) {
     if (n == 0) return FDH_SUCCESS;
     if (!in_off || !out_off || !out_len) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
-    if (!in || !out) return fail(FDH_ERR_INVALID_ARGUMENT, "null data pointer");
+    if (!out) return fail(FDH_ERR_INVALID_ARGUMENT, "null data pointer");  // (`in` may be null for a batch of empty inputs: below)
     if (mode != FDH_MODE_LEVEL1 && mode != FDH_MODE_RLE) return fail(FDH_ERR_INVALID_ARGUMENT, "unknown encoder mode");
     if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many streams in one call");
     if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
@@ -297,6 +297,8 @@ int fdh_deflate_general_batch(const uint8_t* in, const uint64_t* in_off, uint8_t
     HIP_TRY(hipStreamSynchronize(stream));
     if (ends[1] < ends[0]) return fail(FDH_ERR_INVALID_ARGUMENT, "in_off is not ascending");
     const uint64_t total_in = ends[1] - ends[0];
+    // an empty input has a defined encoding (78 01 03 00 00 00 00 01), and a zero-element buffer has no address
+    if (!in && total_in != 0) return fail(FDH_ERR_INVALID_ARGUMENT, "null data pointer");
     // The parser runs one stream per lane and is bound by the latency of dependent loads: with a
     // small batch it is given fewer lanes per wavefront and more wavefronts (8 per CU if the batch
     // allows), capped so that the hash tables of the resident lanes stay below 8 GiB.

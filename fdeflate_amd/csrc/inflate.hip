@@ -792,7 +792,10 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         } else {
             e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
             if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 8 * sizeof(uint32_t), stream);  // counters + second header
-            if (e != hipSuccess) return (int)e;
+            if (e != hipSuccess) {
+                (void)hipFreeAsync(list, stream);
+                return (int)e;
+            }
         }
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->len4, canon->hdr,
                         fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr, canon->nl, canon->lit2, nullptr, nullptr};
@@ -804,12 +807,18 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 uint32_t* counters = list + (n + 4);
                 hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in_off, (uint32_t)n, order, counters);
                 e = hipGetLastError();
-                if (e != hipSuccess) return (int)e;
+                if (e != hipSuccess) {
+                    (void)hipFreeAsync(list, stream);
+                    return (int)e;
+                }
                 sa.order = order;
             }
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
             e = hipGetLastError();
-            if (e != hipSuccess) return (int)e;
+            if (e != hipSuccess) {
+                (void)hipFreeAsync(list, stream);
+                return (int)e;
+            }
             sa.src_list = list;
             sa.list = list + list2_at;
             sa.list2 = nullptr;
@@ -823,7 +832,10 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         if (list) sblocks = std::min(sblocks, (unsigned)(2 * cus));  // persistent wavefronts: two workgroups (80 KiB of LDS each) per CU
         hipLaunchKernelGGL(fdh::inflate_segments_kernel, dim3(sblocks), dim3(fdh::kSegWaves * fdh::kWave), 0, stream, sa);
         e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
+        if (e != hipSuccess) {
+            if (list) (void)hipFreeAsync(list, stream);
+            return (int)e;
+        }
         a.only_pending = 1;
         if (flags & 64u) {  // debug: first kernel only (PENDING streams stay undecoded)
             if (list) (void)hipFreeAsync(list, stream);

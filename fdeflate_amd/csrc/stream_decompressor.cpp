@@ -7,10 +7,10 @@
 //
 //   * input handed to `read` is appended to a device-resident copy of the stream (consumed =
 //     input_len, always: "the input is fully consumed" is the post-condition we pick);
-//   * the stream-so-far is decoded by fdh_inflate_batch (batch of one) into a device slot whose
-//     capacity is exactly what the caller can take now (bytes delivered so far + the room left in
-//     `output`), so the one-shot classification (src/decompress.rs:1126-1139) says which
-//     post-condition holds: Ok -> done; OutputTooLarge -> "the output is full but there are more
+//   * the stream-so-far is decoded by fdh_inflate_batch (batch of one) into a device slot that holds what
+//     the caller can take now (bytes delivered so far + the room left in `output`) and, decoding ahead,
+//     up to as much again + 64 KiB (see below); the one-shot classification (src/decompress.rs:1126-1139)
+//     of the attempt whose prefix is used up says which post-condition holds: Ok -> done; OutputTooLarge -> "the output is full but there are more
 //     bytes"; InsufficientInput -> the engine reports how many bytes the reference had produced when
 //     it ran dry, and exactly those are delivered;
 //   * only output[output_position ..] is written, never more than the room, and the bytes in
@@ -98,6 +98,8 @@ struct fdh_decompressor {
     size_t ahead_in = 0;      // in_len it was decoded from
     uint32_t ahead_st = 0;    // the status of that attempt (for ITS slot)
     uint64_t attempts = 0;    // decode attempts so far (introspection)
+    size_t ahead_bad_cap = 0; // an attempt that decoded ahead into a slot this large met a hard error (0: none):
+    size_t ahead_bad_in = 0;  // ... with this much input buffered; later slots stay below it until more input arrives
 };
 
 extern "C" {
@@ -212,12 +214,27 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
 
     const size_t cap_exact = std::min<size_t>(d->delivered + room, 0xFFFFFFF0ull);
     size_t cap = std::min<size_t>(std::max<size_t>(cap_exact, 2 * d->delivered + 65536), 0xFFFFFFF0ull);
+    // a hard error was met decoding ahead of the caller with this very input: it lies somewhere below that
+    // slot's end, so stay with the exact slot until the window gets there (not two decodes per call)
+    if (d->ahead_bad_cap != 0 && d->ahead_bad_in == d->in_len && cap > cap_exact) {
+        // ... halving the distance to it each time: O(log) attempts up to the damage, as for a good stream
+        const size_t mid = cap_exact + (d->ahead_bad_cap > cap_exact ? (d->ahead_bad_cap - cap_exact) / 2 : 0);
+        cap = mid >= cap_exact + 65536 ? std::min(cap, mid) : cap_exact;
+    }
     HIP_TRY(d->meta.reserve(64, 0));
     // a hipMalloc'd buffer can be empty only before the first byte arrives
     HIP_TRY(d->in.reserve(16, d->in_len));
     uint32_t host_res[4] = {0, 0, 0, 0};
     for (;;) {
-        HIP_TRY(d->out.reserve(cap + 16, 0));  // (every attempt decodes from the first byte: nothing to keep)
+        {   // (every attempt decodes from the first byte: nothing to keep)
+            hipError_t re = d->out.reserve(cap + 16, 0);
+            if (re == hipErrorOutOfMemory && cap != cap_exact) {  // no room to decode ahead: the exact slot may still fit
+                (void)hipGetLastError();
+                cap = cap_exact;
+                re = d->out.reserve(cap + 16, 0);
+            }
+            HIP_TRY(re);
+        }
         uint64_t meta[8] = {0, (uint64_t)d->in_len, 0, (uint64_t)cap, 0, 0, 0, 0};
         HIP_TRY(hipMemcpy(d->meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
         uint64_t* m = reinterpret_cast<uint64_t*>(d->meta.p);
@@ -233,6 +250,8 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
         // a hard error somewhere in the part decoded ahead: the caller must not hear of it before its
         // window gets there -- decode again into exactly what the caller can take
         if (!classified && cap != cap_exact) {
+            d->ahead_bad_cap = cap;
+            d->ahead_bad_in = d->in_len;
             cap = cap_exact;
             continue;
         }

@@ -366,3 +366,6 @@ def test_large_stream_through_a_small_window_decodes_ahead(fd):
         assert got == eout
     else:
         assert eout.startswith(got) and len(got) >= len(eout) - 16_384 and len(got) > 500_000
+        # the damage is met once decoding ahead; from then on the attempts stay with the exact slot instead of
+        # decoding twice per call (round-3 review): about one attempt per call behind that point, not two
+        assert attempts <= 12 + 1 + (len(eout) // 2) // 16_384 + 8, attempts

@@ -6,7 +6,9 @@ cd "$GRAFT_REPO_ROOT"
 [ -n "$LIB" ] && export FDH_LIB=$PWD/$LIB
 OUT=gpurun_out/s2pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/p -- timeout 120 python3 tools/seg2diag.py 65536 D > $OUT/log.txt 2>&1
+# (the program itself behind `--`: with --pmc the profiler's library initialises the GPU before the program starts, and
+#  a launcher in between -- timeout, env, bash -c -- would exec from a process that has touched the GPU; the watchdog goes outside)
+timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/p -- python3 tools/seg2diag.py 65536 D > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv,glob
 from collections import defaultdict
