@@ -81,6 +81,7 @@ struct InflateBatchArgs {
                      // the fast / the 12-bit general kernel, [4..] = ids)
     uint32_t* span_pool;   // nullable: kSpanSlots busy flags, then kSpanSlots match lists (span decoder scratch)
     uint32_t* lz_counter;  // hand-out counter of the LZ-window kernel (zeroed by the launcher)
+    uint2* lz_ck;          // its items: 64 x kLzMaxPhases per wavefront (stream-ordered scratch)
 };
 constexpr uint32_t kSpanSlots = 2048;  // > workgroups of the general kernel resident on one device (256 CUs x 5)
 
@@ -240,6 +241,15 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     InflaterT<kLzLitBits, false> inf(L.tables, *reinterpret_cast<WaveIo*>(&L.u.hdr), &L.u.hdr.hs, lane);
     inf.init(s);
     if (inf.parse_zlib_header() != RC_OK) return false;
+    LzIn lin;
+    lin.base16 = inf.base16;
+    lin.mis = inf.mis;
+    lin.win_bytes = inf.win_bytes;
+    lin.buf_lo = s.buf_lo;
+    lin.buf_hi = s.buf_hi;
+    lin.in_bits = in_bits;
+    lin.cap = s.cap;
+    lin.ck = a.lz_ck + (size_t)blockIdx.x * (kWave * kLzMaxPhases);
     LzOut o;
     o.out_al = inf.out_al;
     o.gmis = inf.gmis;
@@ -285,16 +295,14 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
         const LzBounds bd = lz_load_bounds(L.tables);
         LZT(o, 0);
         if (rc == RC_OK) {
-            uint32_t R = kLzRange;
-            for (uint32_t nspans = 0;; nspans++) {  // spans
+            uint32_t qcap = kLzRange;
+            for (uint32_t nspans = 0;; nspans++) {  // super-spans
                 if (bitpos >= in_bits || nspans > in_bits) return false;
-                const uint32_t fair = (in_bits - bitpos + kWave - 1) / kWave;
-                const uint32_t r = min(R, max(fair, 8u));
-                const uint32_t res = lz_span(L, o, bd, inf.base16, inf.mis, inf.win_bytes, s.buf_lo, s.buf_hi, in_bits, s.cap, bitpos, r, lane);
+                const uint32_t res = lz_superspan(L, o, bd, lin, bitpos, qcap, lane);
                 if (res == LZ_BAIL) return false;
-                if (res == LZ_SHRINK) {
-                    if (r <= 8) return false;
-                    R = max(8u, r / 4);
+                if (res == LZ_SHRINK) {  // an item that does not fit an image: shorter phases from there on
+                    if (qcap <= 8) return false;
+                    qcap = max(8u, qcap / 4);
                     continue;
                 }
                 if (res == LZ_EOB) break;
@@ -732,7 +740,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr};
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr};
     if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
         int ordinal = 0;
         if (hipGetDevice(&ordinal) == hipSuccess && ordinal >= 0 && ordinal < 64) {
@@ -786,7 +794,9 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         const size_t list2_at = (size_t)(n + 4) + 4;
         const size_t list_words = list2_at + (size_t)(n + 4) + (ordered ? (size_t)((n + 1) & ~1ull) : 0);
         const size_t ckpt_bytes = seg2 ? (size_t)s2blocks * fdh::kS2Waves * fdh::kS2CkptPerWave * sizeof(uint2) : 0;
-        if (hipMallocAsync(reinterpret_cast<void**>(&list), list_words * sizeof(uint32_t) + ckpt_bytes, stream) != hipSuccess) {
+        const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);  // LZ-window kernel: persistent wavefronts
+        const size_t lzck_bytes = (flags & 0x1000u) ? 0 : (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
+        if (hipMallocAsync(reinterpret_cast<void**>(&list), list_words * sizeof(uint32_t) + ckpt_bytes + lzck_bytes, stream) != hipSuccess) {
             (void)hipGetLastError();
             list = nullptr;  // fall back to the status-scan form
         } else {
@@ -851,7 +861,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 4096);  // persistent workgroups (16 per CU at most)
             if (e == hipSuccess && !(flags & 0x1000u)) {  // the LZ-window kernel: persistent wavefronts, FDH_LZ_WAVES_PER_CU per CU
                 a.lz_counter = list + (n + 4) + 2;  // (a spare word of stream_order_kernel's counters, zeroed above)
-                const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);
+                a.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + list_words * sizeof(uint32_t) + ckpt_bytes);
                 hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, stream, a);
                 e = hipGetLastError();
             }

@@ -37,7 +37,7 @@ namespace fdh {
 constexpr int kLzLitBits = 10;
 constexpr uint32_t kLzLitMask = (1u << kLzLitBits) - 1;
 #ifndef FDH_LZ_RING
-#define FDH_LZ_RING 8192
+#define FDH_LZ_RING 7168
 #endif
 #ifndef FDH_LZ_WAVES_PER_CU
 #define FDH_LZ_WAVES_PER_CU 7
@@ -51,12 +51,18 @@ constexpr uint32_t kLzLitMask = (1u << kLzLitBits) - 1;
 #ifndef FDH_LZ_WARM
 #define FDH_LZ_WARM 256
 #endif
-constexpr uint32_t kLzRange = FDH_LZ_RANGE;  // stream bits per lane and span: an odd number of dwords, so the lanes' windows start in different LDS banks
+constexpr uint32_t kLzRange = FDH_LZ_RANGE;  // stream bits of a lane's range walked per phase (an item of pass 2)
 constexpr uint32_t kLzWarm = FDH_LZ_WARM;    // bits a guessed chain walks in front of its range
-constexpr uint32_t kLzImgCap = FDH_LZ_IMG;   // output bytes of one span
+constexpr uint32_t kLzImgCap = FDH_LZ_IMG;   // output bytes resolved at a time (an image)
+constexpr int kLzMaxPhases = 16;             // phases of a super-span: a lane's range is at most 16 x kLzRange bits
+static_assert(kLzWarm <= kLzRange, "the warm-up walk uses a lane's stage slot like a phase");
 constexpr uint32_t kLzRing = FDH_LZ_RING;   // history + image, a multiple of 64
 constexpr bool kLzRingPow2 = (kLzRing & (kLzRing - 1)) == 0;
-constexpr uint32_t kLzStageDw = ((64 * kLzRange + 127 + 31) / 32 + 12 + 3) & ~3u;  // the span + what a walk reads beyond it + alignment
+// A lane's stage slot: the dwords of one phase -- 31 bits of alignment + the phase + the 96-bit window of the last
+// step that starts inside it -- an odd number, so that the lanes' slots start in different LDS banks.
+constexpr uint32_t kLzSlotDw = ((31 + kLzRange + 96 + 31) / 32) | 1u;
+constexpr uint32_t kLzStageDw = 64 * kLzSlotDw;
+static_assert(kLzStageDw >= 256, "the far buffer and the header parser borrow the first KiB of the stage");
 constexpr uint32_t kLzIdxCap = kLzImgCap / 4;  // matches of one span (a match is at least three bytes; the bench's zlib-6 streams: one per 5.2)
 static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 1024, "ring = image + history");
 
@@ -291,32 +297,35 @@ __device__ __forceinline__ LzTok lz_token_slow(const TableSetT<kLzLitBits>& T, c
 }
 
 struct LzWalk {
-    uint32_t b;     // first step at or behind the range start
     uint32_t e;     // where the chain left the range (first step at or behind its end), or where it stopped
-    uint32_t cnt;   // output bytes of the steps that start inside the range
+    uint32_t cnt;   // output bytes of the steps taken
     uint32_t nm;    // matches among them
     uint32_t stop;  // 0 none, 1 end-of-block, 2 impossible token / past the end of the input
     uint32_t stop_bits;
 };
 
-// One lane's walk from `pos` (a real step start if `real`) to the first step at or behind `end`;
-// positions are bits relative to the stage.  EMIT: pass 2 -- `q_rel` is the lane's offset in the
-// image, `mi` the index of its first match in the span's list.  `trouble` collects what must never happen on a real chain.
+// One lane's walk from `pos` to the first step at or behind `end`; positions are window bits (stream bit +
+// 8 x the misalignment of the stream's first byte), the lane's stage slot holds the dwords from window
+// dword `slot_dw`.  `slide`: a guessed chain in front of its range slides over impossible tokens by one
+// bit instead of stopping.  EMIT: pass 2 -- `q_rel` is the lane's offset in the image, `mi` the index of
+// its first match in the image's list.  `trouble` collects what must never happen on a real chain.
 //
 // The fast step is branch-free and the same for every lane: a lane in front of a special token (a code
-// beyond a primary table, end-of-block, an impossible token) simply does not advance; every fourth
-// step, or when nobody else moves, those lanes take the slow step, which knows every case.
+// beyond the tables, end-of-block, an impossible token) simply does not advance; every fourth step, or
+// when nobody else moves, those lanes take the slow step, which knows every case.
 template <bool EMIT>
-__device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t pos, const uint32_t s, const uint32_t end, const bool real,
-                                          const bool active, const uint32_t limit, uint32_t q_rel, const uint32_t o_ri,
-                                          const uint32_t o_abs, uint32_t mi, bool& trouble, uint32_t* iters = nullptr, uint32_t* slows = nullptr) {
+__device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t pos, const uint32_t end, const bool slide,
+                                          const bool active, const uint32_t limit, const uint32_t slot_dw, uint32_t q_rel,
+                                          const uint32_t o_ri, const uint32_t o_abs, uint32_t mi, bool& trouble, uint32_t* iters = nullptr,
+                                          uint32_t* slows = nullptr) {
     const TableSetT<kLzLitBits>& T = L.tables;
     LzWalk w;
-    uint32_t b = 0xFFFFFFFFu, cnt = 0, nm = 0, stop = 0, stop_bits = 0;
+    uint32_t cnt = 0, nm = 0, stop = 0, stop_bits = 0;
     bool run = active && pos < end;
     uint32_t it = 0;
     uint32_t dbad = 0;
-
+    const uint32_t* const slot = &L.u.w.stage[kLzSlotDw * (threadIdx.x & 63)];
+    const uint32_t bit0 = slot_dw * 32;
     while (__any(run)) {
         if (++it > 8192) {  // cannot happen; never hang
             trouble = true;
@@ -324,8 +333,8 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
         }
         bool special;
         {
-            const uint32_t di = pos >> 5, sh = pos & 31;
-            const uint32_t r0 = L.u.w.stage[di], r1 = L.u.w.stage[di + 1], r2 = L.u.w.stage[di + 2];
+            const uint32_t rel = run ? pos - bit0 : 0u, di = rel >> 5, sh = rel & 31;
+            const uint32_t r0 = slot[di], r1 = slot[di + 1], r2 = slot[di + 2];
             const uint32_t lo = __builtin_amdgcn_alignbit(r1, r0, sh), hi = __builtin_amdgcn_alignbit(r2, r1, sh);
             uint32_t e = T.lit[lo & kLzLitMask];
             if (__any((e & LZW_TWO) == LZW_TWO)) {  // a code of 11 .. 15 bits: its second-level entry
@@ -340,8 +349,6 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
             const uint32_t bits = tb + (is_len ? (de & 31) : 0u);
             const uint32_t inc = is_len ? length : ((e >> 5) & 3);
             const bool go = run && !special;
-            const bool started = pos >= s;
-            b = min(b, (run && started) ? pos : 0xFFFFFFFFu);
             if (EMIT) {
                 const uint32_t qi = lz_wrap(o_ri + q_rel);
                 if (go && !is_len) {
@@ -358,53 +365,51 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
                     L.u.w.idx[min(mi, kLzIdxCap - 1)] = (uint16_t)q_rel;
                     mi++;
                 }
-                q_rel += go ? inc : 0u;  // (pass 2 starts on its range: every step counts)
+                q_rel += go ? inc : 0u;
             }
-            cnt += (go && started) ? inc : 0u;
-            nm += (go && started && is_len) ? 1u : 0u;
+            cnt += go ? inc : 0u;
+            nm += (go && is_len) ? 1u : 0u;
             pos += go ? bits : 0u;
             run = run && pos < end;
         }
         if ((it & 3) == 0 || !__any(run && !special)) {
             const bool act = run && special;
             if (__any(act)) {
-                const uint32_t di = pos >> 5, sh = pos & 31;
-                const uint32_t r0 = L.u.w.stage[di], r1 = L.u.w.stage[di + 1], r2 = L.u.w.stage[di + 2];
+                const uint32_t rel = act ? pos - bit0 : 0u, di = rel >> 5, sh = rel & 31;
+                const uint32_t r0 = slot[di], r1 = slot[di + 1], r2 = slot[di + 2];
                 const uint32_t lo = __builtin_amdgcn_alignbit(r1, r0, sh), hi = __builtin_amdgcn_alignbit(r2, r1, sh);
                 const LzTok tk = lz_token_slow(T, L.sub, bd, lo, hi);
                 if (slows) *slows += 1;
-                const bool started = pos >= s;
                 if (act) {
                     if (tk.kind >= 2) {
-                        if (!started && !real) {
+                        if (slide) {
                             pos += 1;  // a guessed chain in front of its range: slide on
+                            run = pos < end;
                         } else {
                             stop = tk.kind == 2 ? 1u : 2u;
                             stop_bits = tk.bits;
                             run = false;
                         }
                     } else {
-                        if (started) {
-                            cnt += tk.n;
-                            if (EMIT) {
-                                const uint32_t qi = lz_wrap(o_ri + q_rel);
-                                if (tk.kind == 0) {
-                                    L.ring[qi] = (uint8_t)tk.v;
-                                    if (tk.n == 2) L.ring[lz_wrap(qi + 1)] = (uint8_t)(tk.v >> 8);
-                                } else {
-                                    const uint32_t length = tk.v & 0xFFFF, dist = tk.v >> 16;
-                                    dbad |= dist > o_abs + q_rel ? 1u : 0u;
-                                    const uint32_t d = (length - 3) | ((dist - 1) << 8);
-                                    L.ring[qi] = (uint8_t)d;
-                                    L.ring[qi + 1] = (uint8_t)(d >> 8);
-                                    L.ring[qi + 2] = (uint8_t)(d >> 16);
-                                    L.u.w.idx[min(mi, kLzIdxCap - 1)] = (uint16_t)q_rel;
-                                    mi++;
-                                }
-                                q_rel += tk.n;
+                        cnt += tk.n;
+                        if (EMIT) {
+                            const uint32_t qi = lz_wrap(o_ri + q_rel);
+                            if (tk.kind == 0) {
+                                L.ring[qi] = (uint8_t)tk.v;
+                                if (tk.n == 2) L.ring[lz_wrap(qi + 1)] = (uint8_t)(tk.v >> 8);
+                            } else {
+                                const uint32_t length = tk.v & 0xFFFF, dist = tk.v >> 16;
+                                dbad |= dist > o_abs + q_rel ? 1u : 0u;
+                                const uint32_t d = (length - 3) | ((dist - 1) << 8);
+                                L.ring[qi] = (uint8_t)d;
+                                L.ring[qi + 1] = (uint8_t)(d >> 8);
+                                L.ring[qi + 2] = (uint8_t)(d >> 16);
+                                L.u.w.idx[min(mi, kLzIdxCap - 1)] = (uint16_t)q_rel;
+                                mi++;
                             }
-                            nm += tk.kind == 1 ? 1u : 0u;
+                            q_rel += tk.n;
                         }
+                        nm += tk.kind == 1 ? 1u : 0u;
                         pos += tk.bits;
                         run = pos < end;
                     }
@@ -414,7 +419,6 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
     }
     if (dbad) trouble = true;
     if (pos > limit && stop == 0 && active) stop = 2;  // ran past the end of the input (zeros are staged there)
-    w.b = b == 0xFFFFFFFFu ? pos : b;
     w.e = pos;
     w.cnt = cnt;
     w.nm = nm;
@@ -451,6 +455,40 @@ __device__ __forceinline__ uint4 lz_load16(const uint8_t* base16, uint64_t w0, u
         }
     }
     return v;
+}
+
+// The dwords of a lane's next walk into its stage slot: kLzSlotDw dwords from window dword `dw` (zero beyond
+// the stream, careful at the ends of the packed batch).  Returns `dw`.
+struct __attribute__((packed, aligned(4))) LzU4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ uint32_t lz_stage_slot(LzLds& L, const bool active, const uint32_t pos, const uint8_t* base16,
+                                                  const uint64_t win_bytes, const uint8_t* buf_lo, const uint8_t* buf_hi, const int lane) {
+    const uint32_t dw = pos >> 5;
+    uint32_t* const slot = &L.u.w.stage[kLzSlotDw * (uint32_t)lane];
+    if (active) {
+#pragma unroll
+        for (uint32_t k = 0; k < kLzSlotDw; k += 4) {
+            const uint64_t w0 = ((uint64_t)dw + k) * 4;
+            const uint8_t* p = base16 + w0;
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (w0 + 16 <= win_bytes && p >= buf_lo && p + 16 <= buf_hi) {
+                const LzU4 q = *reinterpret_cast<const LzU4*>(p);
+                v[0] = q.x;
+                v[1] = q.y;
+                v[2] = q.z;
+                v[3] = q.w;
+            } else {
+                for (int j = 0; j < 16; j++) {
+                    if (w0 + j < win_bytes && p + j >= buf_lo && p + j < buf_hi) v[j >> 2] |= (uint32_t)p[j] << (8 * (j & 3));
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (k + j < kLzSlotDw) slot[k + j] = v[j];
+        }
+    }
+    return dw;
 }
 
 // ---- dynamic block header, this kernel's own: code-length code in registers, tables filled by index ----
@@ -800,10 +838,10 @@ __device__ __forceinline__ void lz_batch_plan(LzLds& L, LzBatch& B, LzFar& Fr, c
     B.dist = dist;
     B.send = pos - dist + min(len, dist);
     const int32_t src = (int32_t)(O + pos - dist);  // >= 0 (pass 2 checked it)
-    const bool small = valid && len <= 16 && dist >= len && qi0 + 16 <= kLzRing && sidx0 + 16 <= kLzRing;
-    const bool far = small && src + (int32_t)len <= ring_lo;
+    const bool small = valid && len <= 16 && dist >= len && qi0 + 16 <= kLzRing;
+    const bool far = small && src + (int32_t)len <= ring_lo;  // (its ring index means nothing: the distance may exceed the ring)
     B.far = far;
-    B.simple = small && (far || src >= ring_lo);
+    B.simple = far || (small && src >= ring_lo && sidx0 + 16 <= kLzRing);
     const uint32_t ring_at = (uint32_t)(reinterpret_cast<uintptr_t>(&L.ring[0]) & 0xFFFFu);
     const uint32_t far_at = (uint32_t)(reinterpret_cast<uintptr_t>(&L.u.w.stage[0]) & 0xFFFFu);
     B.sbase = far ? far_at + 16u * (uint32_t)lane : ring_at + sidx0;
@@ -868,6 +906,9 @@ __device__ __forceinline__ void lz_batch_fill(LzLds& L, const LzBatch& B, const 
 #pragma unroll
         for (int x = 32; x > 0; x >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, x, kWave));
         longest = uni(longest);
+        // (every lane stores every byte: a byte that is not wanted goes to a spare byte behind the ring -- a
+        //  select per byte instead of an execution mask per byte)
+        const uint32_t n = go ? B.len : 0u;
 #pragma unroll
         for (int k0 = 0; k0 < 16; k0 += 4) {
             if ((uint32_t)k0 >= longest) break;
@@ -875,8 +916,7 @@ __device__ __forceinline__ void lz_batch_fill(LzLds& L, const LzBatch& B, const 
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = sp[k0 + k];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (go && (uint32_t)(k0 + k) < B.len) L.ring[B.qi0 + k0 + k] = (uint8_t)v[k];
+            for (int k = 0; k < 4; k++) L.ring[(uint32_t)(k0 + k) < n ? B.qi0 + k0 + k : kLzRing + 12] = (uint8_t)v[k];
         }
     };
     const bool indep = B.simple && (B.far || (int32_t)B.send <= (int32_t)F);
@@ -903,69 +943,134 @@ __device__ __forceinline__ void lz_batch_fill(LzLds& L, const LzBatch& B, const 
 
 enum : uint32_t { LZ_MORE = 0, LZ_EOB = 1, LZ_BAIL = 2, LZ_SHRINK = 3 };
 
-// One span of the current block from stream bit `bitpos`.  LZ_MORE / LZ_EOB: `bitpos` advanced, the
-// image resolved, flushed and part of the history.  LZ_SHRINK: not even lane 0 fits the image with
-// this R.  LZ_BAIL: this stream is for the exact kernels.
-__device__ __forceinline__ uint32_t lz_span(LzLds& L, LzOut& o, const LzBounds& bd, const uint8_t* base16, const uint32_t mis,
-                                            const uint64_t win_bytes, const uint8_t* buf_lo, const uint8_t* buf_hi,
-                                            const uint32_t in_bits, const uint32_t cap, uint32_t& bitpos, const uint32_t R,
-                                            const int lane) {
-    // ---- stage the span's bytes ----
-    const uint32_t wbit = bitpos + mis * 8;       // window bit of the span's first bit
-    const uint32_t c0 = (wbit >> 5) & ~3u;        // first staged dword, 16-B aligned
-    const uint32_t rel0 = wbit - c0 * 32;         // the span's first bit, relative to the stage
-    const uint32_t limit = in_bits + mis * 8 - c0 * 32;
-    const uint32_t need_dw = min((uint32_t)kLzStageDw, ((rel0 + kWave * R + 31) / 32 + 12 + 3) & ~3u);
-    wave_sync();
-    for (uint32_t i = (uint32_t)lane * 4; i < need_dw; i += kWave * 4) {
-        const uint4 v = lz_load16(base16, ((uint64_t)c0 + i) * 4, win_bytes, buf_lo, buf_hi);
-        *reinterpret_cast<uint4*>(&L.u.w.stage[i]) = v;
-    }
-    wave_sync();
-    LZT(o, 1);
-    // ---- pass 1 ----
-    const uint32_t s = rel0 + (uint32_t)lane * R, end = s + R;
+struct LzIn {
+    const uint8_t* base16;  // 16-B aligned address at or below the stream's first byte
+    uint32_t mis;           // the stream's first byte = base16 + mis
+    uint64_t win_bytes;     // mis + length of the stream
+    const uint8_t* buf_lo;  // readable range of the packed batch
+    const uint8_t* buf_hi;
+    uint32_t in_bits;
+    uint32_t cap;           // capacity of the output slot
+    uint2* ck;              // this wavefront's checkpoints: 64 x kLzMaxPhases items
+};
+
+// One SUPER-SPAN of the current block from stream bit `bitpos`: the next 64 x P x Q stream bits, lane l owning the
+// P x Q bits from bitpos + l P Q and walking them in P phases of Q bits (Q = kLzRange unless little input is left).
+//
+//   pass 1   a lane walks a guessed chain from up to kLzWarm bits in front of its range to its range (sliding over
+//            impossible tokens), then phase by phase through it, leaving an ITEM per phase in global scratch:
+//            where the phase's first step starts, the output bytes and matches of the steps that start in it.
+//   check    a lane's first step must be where its left neighbour's chain left the neighbour's range; lanes that
+//            fail walk again from there until they meet their old chain at a phase boundary (the items behind
+//            that boundary stand).  Once per super-span -- not once per image as in the first version of this
+//            kernel, whose warm-up and re-walks were 46 % of its time.
+//   items    lane-major order is stream order; 64 items at a time (as many as fit the image): offsets by prefix
+//            sums, pass 2 (every lane walks one item), resolve, flush.
+//
+// LZ_MORE / LZ_EOB: `bitpos` advanced, everything decoded is resolved, flushed and part of the history.
+// LZ_SHRINK: the item at `bitpos` (advanced to it) does not fit an image: again with a smaller Q.
+// LZ_BAIL: this stream is for the exact kernels.
+__device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBounds& bd, const LzIn& in, uint32_t& bitpos,
+                                                 const uint32_t qcap, const int lane) {
+    const uint32_t mis8 = in.mis * 8;
+    const uint32_t w0 = bitpos + mis8, limit = in.in_bits + mis8;  // window bits
+    const uint32_t fair = (limit - w0 + kWave - 1) / kWave;
+    const uint32_t Q = max(8u, min(min(fair, qcap), kLzRange));
+    const uint32_t P = max(1u, min((uint32_t)kLzMaxPhases, (fair + Q - 1) / Q));
+    const uint32_t R = Q * P;
+    const uint32_t s = w0 + (uint32_t)lane * R;
     const bool live = s < limit;
-    const uint32_t ws = (s - rel0 > kLzWarm) ? s - kLzWarm : rel0;
+    uint2* const ck = in.ck + (uint32_t)lane * P;  // this lane's items
     bool trouble = false;
     uint32_t iters = 0, slows = 0;
-    LzWalk w = lz_walk<false>(L, bd, ws, s, end, ws == rel0, live, limit, 0, 0, 0, 0, trouble, &iters, &slows);
-    if (!live) {
-        w.b = w.e = s;
-        w.cnt = w.nm = 0;
-        w.stop = 2;
+    auto stage = [&](const bool act, const uint32_t pos) __attribute__((always_inline)) -> uint32_t {
+        wave_sync();
+        const uint32_t dw = lz_stage_slot(L, act, pos, in.base16, in.win_bytes, in.buf_lo, in.buf_hi, lane);
+        wave_sync();
+        return dw;
+    };
+    // ---- pass 1: warm-up, then the phases ----
+    uint32_t pos, stop = 0, stop_bits = 0, b;
+    {
+        const uint32_t ws = (s - w0 > kLzWarm) ? s - kLzWarm : w0;
+        const bool act = live && ws < s;
+        const uint32_t dw = stage(act, ws);
+        const LzWalk w = lz_walk<false>(L, bd, ws, s, ws != w0, act, limit, dw, 0, 0, 0, 0, trouble, &iters, &slows);
+        pos = act ? w.e : s;
+        if (act && w.stop) {  // a real chain that stops in front of this range: the block ends in a lane to the left
+            stop = w.stop;
+            stop_bits = w.stop_bits;
+        }
+        if (!live) stop = 2;
+        b = pos;
     }
+    LZT(o, 1);
+    for (uint32_t p = 0; p < P; p++) {
+        const uint32_t end = s + Q * (p + 1);
+        const bool act = live && stop == 0 && pos < end;
+        const uint32_t dw = stage(act, pos);
+        const LzWalk w = lz_walk<false>(L, bd, pos, end, false, act, limit, dw, 0, 0, 0, 0, trouble, &iters, &slows);
+        ck[p] = make_uint2(pos, act ? (w.cnt | (w.nm << 16)) : 0u);
+        if (act) {
+            pos = w.e;
+            stop = w.stop;
+            stop_bits = w.stop_bits;
+        }
+    }
+    uint32_t e = pos;
     LZT(o, 2);
     // ---- check, fix-up rounds ----
-    uint32_t start = w.b;
     int first_stop = kWave;
     bool converged = false;
     for (int round = 0; round <= kWave; round++) {
-        const uint32_t prev_e = __shfl_up(w.e, 1, kWave), prev_stop = __shfl_up(w.stop, 1, kWave);
-        const bool ok = lane == 0 || (prev_stop == 0 && start == prev_e);
+        const uint32_t prev_e = __shfl_up(e, 1, kWave), prev_stop = __shfl_up(stop, 1, kWave);
+        const bool ok = lane == 0 || (prev_stop == 0 && b == prev_e);
         const uint64_t bad_mask = __ballot(!ok);
         const int first_bad = bad_mask ? __ffsll((unsigned long long)bad_mask) - 1 : kWave;
-        const uint64_t stop_mask = __ballot(w.stop != 0) & (first_bad < kWave ? lanemask_lt(first_bad) : ~0ull);
+        const uint64_t stop_mask = __ballot(stop != 0) & (first_bad < kWave ? lanemask_lt(first_bad) : ~0ull);
         first_stop = stop_mask ? __ffsll((unsigned long long)stop_mask) - 1 : kWave;
         if (first_stop < kWave || first_bad == kWave) {
             converged = true;
             break;
         }
-        const bool redo = !ok && prev_stop == 0;
+        const bool redo = !ok && prev_stop == 0 && live;
         LZC(o, 10, 1);
-        const bool empty = redo && prev_e >= end;  // the neighbour's last step covers this whole range
-        const LzWalk w2 = lz_walk<false>(L, bd, prev_e, s, end, true, redo && !empty, limit, 0, 0, 0, 0, trouble, &iters, &slows);
-        if (redo) {
-            start = prev_e;
-            if (empty) {
-                w.b = w.e = prev_e;
-                w.cnt = w.nm = 0;
-                w.stop = 0;
-                w.stop_bits = 0;
-            } else {
-                w = w2;
-                w.b = prev_e;
+        // the lane walks again from where its neighbour's chain arrived, phase by phase, until it stands on the
+        // first step of one of its old items (from there on the old chain is the real one) or leaves its range
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the items are read back below
+        uint32_t np = redo ? prev_e : 0u, nstop = 0, nstop_bits = 0;
+        bool walking = redo;
+        if (redo) b = prev_e;
+        for (uint32_t p = 0; p < P; p++) {
+            const uint32_t end = s + Q * (p + 1);
+            if (!__any(walking)) break;
+            uint32_t old_pos = 0;
+            if (walking && p != 0) old_pos = __hip_atomic_load(&ck[p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (walking && p != 0 && old_pos == np) walking = false;  // met the old chain: the items from p on stand
+            const bool act = walking && np < end;
+            const uint32_t dw = stage(act, np);
+            const LzWalk w = lz_walk<false>(L, bd, np, end, false, act, limit, dw, 0, 0, 0, 0, trouble, &iters, &slows);
+            if (walking) {
+                ck[p] = make_uint2(np, act ? (w.cnt | (w.nm << 16)) : 0u);
+                if (act) {
+                    np = w.e;
+                    if (w.stop) {
+                        nstop = w.stop;
+                        nstop_bits = w.stop_bits;
+                        // (the items behind a stop are never looked at; make them empty all the same)
+                        for (uint32_t q = p + 1; q < P; q++) ck[q] = make_uint2(np, 0u);
+                        walking = false;
+                        e = np;
+                        stop = nstop;
+                        stop_bits = nstop_bits;
+                    }
+                }
             }
+        }
+        if (walking) {  // never met the old chain: a new end
+            e = np;
+            stop = 0;
+            stop_bits = 0;
         }
     }
     LZT(o, 3);
@@ -974,35 +1079,57 @@ __device__ __forceinline__ uint32_t lz_span(LzLds& L, LzOut& o, const LzBounds& 
     LZC(o, 23, slows);
     if (!converged || __any(trouble)) return LZ_BAIL;
     const int nvalid = first_stop < kWave ? first_stop + 1 : kWave;
-    if (first_stop < kWave && __builtin_amdgcn_readlane(w.stop, first_stop) == 2) return LZ_BAIL;  // a bad token on the real chain
-    // ---- offsets (bytes in the low 22 bits, matches above: a lane's range holds < 2^20 bytes, < 2^9 matches) ----
-    const uint32_t cnt = lane < nvalid ? w.cnt : 0, nm = lane < nvalid ? w.nm : 0;
-    uint64_t incl64 = (uint64_t)cnt | ((uint64_t)nm << 32);
+    const uint32_t fs_kind = first_stop < kWave ? __builtin_amdgcn_readlane(stop, first_stop) : 0u;
+    if (fs_kind == 2) return LZ_BAIL;  // a bad token on the real chain
+    const uint32_t end_pos = __builtin_amdgcn_readlane(e, nvalid - 1);
+    const uint32_t end_bits = fs_kind == 1 ? __builtin_amdgcn_readlane(stop_bits, nvalid - 1) : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the items in stream order, an image at a time ----
+    const uint32_t T = (uint32_t)nvalid * P;
+    const uint32_t recipP = 65536u / P + 1;  // t / P for t < 1024
+    uint32_t t0 = 0;
+    while (t0 < T) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        const bool have = t < T;
+        uint2 item = make_uint2(0, 0);
+        if (have) {
+            const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(in.ck + t), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+            item = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
+        }
+        const uint32_t cnt = item.y & 0xFFFF, nm = item.y >> 16;
+        uint64_t incl64 = (uint64_t)cnt | ((uint64_t)nm << 32);
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint64_t y = __shfl_up(incl64, d, kWave);
-        if (lane >= d) incl64 += y;
-    }
-    const uint32_t incl = (uint32_t)incl64, incl_m = (uint32_t)(incl64 >> 32);
-    const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
-    if (total > cap - o.O) return LZ_BAIL;  // OutputTooLarge is the exact kernels' business
-    const int nuse = __popcll(__ballot(lane < nvalid && incl <= kLzImgCap && incl_m <= kLzIdxCap));
-    if (nuse == 0) return LZ_SHRINK;
-    const uint32_t N = __builtin_amdgcn_readlane(incl, nuse - 1), nmatch = __builtin_amdgcn_readlane(incl_m, nuse - 1);
-    // ---- pass 2 ----
-    wave_sync();
-    LZT(o, 4);
-    const bool mine = lane < nuse;
-    {
-        uint32_t it2 = 0, sl2 = 0;
-        const LzWalk w2 = lz_walk<true>(L, bd, start, start, end, true, mine && start < end, limit, incl - cnt, o.o_ri, o.O, incl_m - nm, trouble, &it2, &sl2);
-        LZC(o, 20, it2);
-        LZC(o, 22, sl2);
-        const bool same = start >= end || (w2.e == w.e && w2.cnt == w.cnt && w2.nm == w.nm && w2.stop == w.stop);
-        if (__any((mine && !same) || trouble)) return LZ_BAIL;  // the passes disagree: a bug, never publish
-    }
-    wave_sync();
-    LZT(o, 5);
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint64_t y = __shfl_up(incl64, d, kWave);
+            if (lane >= d) incl64 += y;
+        }
+        const uint32_t incl = (uint32_t)incl64, incl_m = (uint32_t)(incl64 >> 32);
+        const int nuse = __popcll(__ballot(have && incl <= kLzImgCap && incl_m <= kLzIdxCap));
+        if (nuse == 0) {  // the first item alone is too much for an image: again from there, with shorter phases
+            bitpos = __builtin_amdgcn_readfirstlane(item.x) - mis8;
+            return LZ_SHRINK;
+        }
+        const uint32_t N = __builtin_amdgcn_readlane(incl, nuse - 1), nmatch = __builtin_amdgcn_readlane(incl_m, nuse - 1);
+        if (N > in.cap - o.O) return LZ_BAIL;  // OutputTooLarge is the exact kernels' business
+        LZT(o, 4);
+        // ---- pass 2 ----
+        const bool mine = lane < nuse && cnt != 0;
+        {
+            uint32_t owner = (t * recipP) >> 16;
+            owner = owner * P > t ? owner - 1 : owner;
+            owner = (owner + 1) * P <= t ? owner + 1 : owner;
+            const uint32_t phase = t - owner * P;
+            const uint32_t end = w0 + owner * R + Q * (phase + 1);
+            const uint32_t dw = stage(mine, item.x);
+            uint32_t it2 = 0, sl2 = 0;
+            const LzWalk w2 = lz_walk<true>(L, bd, item.x, end, false, mine, limit, dw, incl - cnt, o.o_ri, o.O, incl_m - nm, trouble, &it2, &sl2);
+            LZC(o, 20, it2);
+            LZC(o, 22, sl2);
+            if (__any((mine && (w2.cnt != cnt || w2.nm != nm)) || trouble)) return LZ_BAIL;  // the passes disagree: a bug, never publish
+        }
+        wave_sync();
+        LZT(o, 5);
     // ---- resolve the matches: 64 at a time in stream order, planned a batch ahead ----
     if (nmatch != 0) {
         const uint32_t O = o.O;
@@ -1028,17 +1155,17 @@ __device__ __forceinline__ uint32_t lz_span(LzLds& L, LzOut& o, const LzBounds& 
         }
         LZC(o, 12, rounds);
     }
-    wave_sync();
-    LZT(o, 6);
-    // ---- the image becomes history; where the stream continues ----
-    o.O += N;
-    o.o_ri = lz_wrap(o.o_ri + N);
-    lz_flush(L, o, false, lane);
-    LZT(o, 7);
-    const uint32_t last_e = __builtin_amdgcn_readlane(w.e, nuse - 1), last_sb = __builtin_amdgcn_readlane(w.stop_bits, nuse - 1);
-    const bool eob = nuse == nvalid && first_stop < kWave;
-    bitpos = last_e + (eob ? last_sb : 0u) - rel0 + bitpos;
-    return eob ? LZ_EOB : LZ_MORE;
+        wave_sync();
+        LZT(o, 6);
+        // ---- the image becomes history ----
+        o.O += N;
+        o.o_ri = lz_wrap(o.o_ri + N);
+        lz_flush(L, o, false, lane);
+        LZT(o, 7);
+        t0 += (uint32_t)nuse;
+    }
+    bitpos = end_pos + end_bits - mis8;
+    return fs_kind == 1 ? LZ_EOB : LZ_MORE;
 }
 
 }  // namespace fdh
