@@ -68,7 +68,7 @@ static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 1024, "ring = image + 
 
 struct __attribute__((aligned(16))) LzWork {
     uint32_t stage[kLzStageDw];    // the span's stream bytes (coalesced copy)
-    uint16_t idx[kLzIdxCap];       // where the span's matches start in the image, in stream order
+    uint16_t idx[kLzIdxCap + 2];   // where the image's matches start, in stream order (+ a spare entry for stores that are not wanted)
 };
 constexpr uint32_t kLzSub = 512;  // second-level entries of the literal/length table (codes of 11 .. 15 bits)
 struct __attribute__((aligned(16))) LzLds {
@@ -350,21 +350,20 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
             const uint32_t inc = is_len ? length : ((e >> 5) & 3);
             const bool go = run && !special;
             if (EMIT) {
+                // every lane stores three bytes and a list entry, whatever its token: what is not wanted goes to a
+                // spare byte behind the ring / a spare entry behind the list (a select instead of an execution mask)
                 const uint32_t qi = lz_wrap(o_ri + q_rel);
-                if (go && !is_len) {
-                    L.ring[qi] = (uint8_t)(e >> 8);
-                    if (inc == 2) L.ring[lz_wrap(qi + 1)] = (uint8_t)(e >> 16);
-                }
-                if (go && is_len) {
-                    const uint32_t dist = (de >> 16) + __builtin_amdgcn_ubfe(dv, (de >> 5) & 15, (de >> 9) & 15);
-                    dbad |= dist > o_abs + q_rel ? 1u : 0u;  // src/decompress.rs:782: the exact kernels report it
-                    const uint32_t d = (length - 3) | ((dist - 1) << 8);
-                    L.ring[qi] = (uint8_t)d;  // (past the ring's end: the guard bytes)
-                    L.ring[qi + 1] = (uint8_t)(d >> 8);
-                    L.ring[qi + 2] = (uint8_t)(d >> 16);
-                    L.u.w.idx[min(mi, kLzIdxCap - 1)] = (uint16_t)q_rel;
-                    mi++;
-                }
+                const uint32_t dist = (de >> 16) + __builtin_amdgcn_ubfe(dv, (de >> 5) & 15, (de >> 9) & 15);
+                const bool gm = go && is_len;
+                dbad |= (gm && dist > o_abs + q_rel) ? 1u : 0u;  // src/decompress.rs:782: the exact kernels report it
+                const uint32_t d = (length - 3) | ((dist - 1) << 8);  // a match leaves its descriptor (past the ring's end: guard bytes)
+                const uint32_t v3 = is_len ? d : (e >> 8);
+                const uint32_t a1 = is_len ? qi + 1 : lz_wrap(qi + 1);
+                L.ring[go ? qi : kLzRing + 12] = (uint8_t)v3;
+                L.ring[(gm || (go && inc == 2)) ? a1 : kLzRing + 12] = (uint8_t)(v3 >> 8);
+                L.ring[gm ? qi + 2 : kLzRing + 12] = (uint8_t)(v3 >> 16);
+                L.u.w.idx[gm ? min(mi, kLzIdxCap - 1) : kLzIdxCap] = (uint16_t)q_rel;
+                mi += gm ? 1u : 0u;
                 q_rel += go ? inc : 0u;
             }
             cnt += go ? inc : 0u;
@@ -764,6 +763,7 @@ __device__ __forceinline__ void lz_flush(LzLds& L, LzOut& o, const bool final, c
     const uint32_t it0 = q_lo & ~15u;
     // ring index of q-space position it0 (q = position + gmis; ring index = q mod kLzRing)
     uint32_t ri = lz_back(o.o_ri, o.O + o.gmis - it0);  // (the distance is < kLzRing: an image + 15)
+    uint64_t acc_a = 0, acc_b = 0;
     for (uint32_t it = it0; it < q_hi; it += kWave * 16) {
         const uint32_t lq = it + (uint32_t)lane * 16;
         const uint32_t lri = lz_wrap(ri + (uint32_t)lane * 16);
@@ -791,11 +791,22 @@ __device__ __forceinline__ void lz_flush(LzLds& L, LzOut& o, const bool final, c
                 }
             }
         }
-        const uint32_t S = wave_sum_u32(s), Tt = wave_sum_u32(t);
-        const uint32_t Lb = blk_hi - blk_lo;
-        o.adler_b = (uint32_t)(((uint64_t)o.adler_b + (uint64_t)Lb * o.adler_a + Tt) % kAdlerMod);
-        o.adler_a = (o.adler_a + S) % kAdlerMod;
+        // (per-lane partial sums; the wavefront adds them up and reduces modulo 65521 once per flush: an image
+        //  is a few KiB, the sums stay far below 2^64)
+        acc_a += s;
+        acc_b += (uint64_t)t + (uint64_t)s * (q_hi - blk_hi);  // the bytes of this block weigh (q_hi - blk_hi) more, seen from the flush's end
         ri = lz_wrap(ri + kWave * 16);
+    }
+    {
+        uint64_t A = acc_a, Bv = acc_b;
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) {
+            A += __shfl_xor(A, x, kWave);
+            Bv += __shfl_xor(Bv, x, kWave);
+        }
+        const uint64_t Lf = q_hi - q_lo;  // bytes of this flush
+        o.adler_b = (uint32_t)(((uint64_t)o.adler_b + Lf * o.adler_a + Bv) % kAdlerMod);
+        o.adler_a = (uint32_t)((o.adler_a + A) % kAdlerMod);
     }
     o.flushed = q_hi - o.gmis;
     wave_sync();
@@ -902,10 +913,7 @@ __device__ __forceinline__ void lz_batch_fill(LzLds& L, const LzBatch& B, const 
     auto copy = [&](const bool go) __attribute__((always_inline)) {
         // go: simple matches only.  Reads first, then writes (a round's sources are never its destinations);
         // four bytes at a time, as far as the longest match of the round needs
-        uint32_t longest = go ? B.len : 0u;
-#pragma unroll
-        for (int x = 32; x > 0; x >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, x, kWave));
-        longest = uni(longest);
+        const uint32_t longest = __any(go && B.len > 12) ? 16u : __any(go && B.len > 8) ? 12u : __any(go && B.len > 4) ? 8u : 4u;
         // (every lane stores every byte: a byte that is not wanted goes to a spare byte behind the ring -- a
         //  select per byte instead of an execution mask per byte)
         const uint32_t n = go ? B.len : 0u;
