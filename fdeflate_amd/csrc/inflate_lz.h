@@ -37,16 +37,16 @@ namespace fdh {
 constexpr int kLzLitBits = 10;
 constexpr uint32_t kLzLitMask = (1u << kLzLitBits) - 1;
 #ifndef FDH_LZ_RING
-#define FDH_LZ_RING 7168
+#define FDH_LZ_RING 4608
 #endif
 #ifndef FDH_LZ_WAVES_PER_CU
-#define FDH_LZ_WAVES_PER_CU 7
+#define FDH_LZ_WAVES_PER_CU 8
 #endif
 #ifndef FDH_LZ_RANGE
-#define FDH_LZ_RANGE 288
+#define FDH_LZ_RANGE 256
 #endif
 #ifndef FDH_LZ_IMG
-#define FDH_LZ_IMG 4096
+#define FDH_LZ_IMG 3584
 #endif
 #ifndef FDH_LZ_WARM
 #define FDH_LZ_WARM 256
