@@ -82,6 +82,7 @@ struct InflateBatchArgs {
     uint32_t* span_pool;   // nullable: kSpanSlots busy flags, then kSpanSlots match lists (span decoder scratch)
     uint32_t* lz_counter;  // hand-out counter of the LZ-window kernel (zeroed by the launcher)
     uint2* lz_ck;          // its items: 64 x kLzMaxPhases per wavefront (stream-ordered scratch)
+    uint32_t* list_out;    // nullable: where the LZ-window kernel lists what it leaves ([0] = count, [4..] = ids)
 };
 constexpr uint32_t kSpanSlots = 2048;  // > workgroups of the general kernel resident on one device (256 CUs x 5)
 
@@ -234,11 +235,15 @@ __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_genera
 __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, const uint64_t sid) {
     const int lane = threadIdx.x;
     if (sid >= a.n) return false;
-    if (a.only_pending && a.status[sid] != kPending) return false;
+    if (a.only_pending) {  // finished by a kernel in front: nothing to do; left for the exact serial decoder: not ours
+        const uint32_t st = a.status[sid];
+        if (st != kPending) return st != kPendingSerial;
+    }
     const StreamArgs s = stream_args(a, sid);
     if (s.in_len < 8 || s.in_len >= (1ull << 27) || s.cap >= (1u << 30) || s.cap < 16) return false;  // 32-bit bit positions; far sources are read 16 bytes at a time
     const uint32_t in_bits = (uint32_t)s.in_len * 8;
-    InflaterT<kLzLitBits, false> inf(L.tables, *reinterpret_cast<WaveIo*>(&L.u.hdr), &L.u.hdr.hs, lane);
+    // (the wave-serial reader is used for its bit window only: zlib header, block type, trailer)
+    InflaterT<kLitBits, false> inf(*reinterpret_cast<TableSetT<kLitBits>*>(&L), *reinterpret_cast<WaveIo*>(&L.u.hdr), nullptr, lane);
     inf.init(s);
     if (inf.parse_zlib_header() != RC_OK) return false;
     LzIn lin;
@@ -259,6 +264,7 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     o.adler_a = 1;
     o.adler_b = 0;
     uint32_t bitpos = 16;
+    bool fixed_built = false;
 #ifdef FDH_LZ_DEBUG
     o.tq = clock64();
 #endif
@@ -267,27 +273,31 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
         if (inf.left < 10) return false;
         const uint32_t type = ((uint32_t)inf.bb >> 1) & 3;
         if (type == 0 || type == 3) return false;  // stored blocks: the kernels behind
-        uint32_t rc;
+        uint32_t rc = RC_OK;
+        inf.last_block = ((uint32_t)inf.bb & 1) != 0;
         if (type == 2) {  // dynamic: this kernel's own parser and table builder
             if (inf.left < 17) return false;
-            inf.last_block = ((uint32_t)inf.bb & 1) != 0;
             const uint32_t hlit = (((uint32_t)inf.bb >> 3) & 31) + 257, hdist = (((uint32_t)inf.bb >> 8) & 31) + 1;
             const uint32_t hclen = (((uint32_t)inf.bb >> 13) & 15) + 4;
             if (hlit > 286 || hdist > 30) return false;
             inf.consume(17);
-            inf.fixed_built = false;
+            fixed_built = false;
             LZT(o, 0);
             if (!lz_parse_dynamic(L, inf, hlit, hdist, hclen, lane, o)) return false;
             lz_build_sub(L, lane);
             LZT(o, 17);
-            rc = RC_OK;
-        } else {
-            const bool had_fixed = inf.fixed_built;
-            rc = inf.parse_block_header();
-            if (rc != RC_OK && rc != RC_EOB) return false;
-            if (rc == RC_OK && !had_fixed) {  // freshly built: the walk's entry layout (fixed codes: nothing beyond the index)
-                lz_convert_tables(L.tables, lane);
+        } else {  // fixed: the same builder on the lengths of src/tables.rs:207-232 (an empty block is one end-of-block token)
+            inf.consume(3);
+            if (!fixed_built) {
+                uint32_t ll[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t sy = (uint32_t)lane + 64u * k;
+                    ll[k] = sy < 144 ? 8u : sy < 256 ? 9u : sy < 280 ? 7u : sy < 288 ? 8u : 0u;
+                }
+                if (!lz_build_tables(L, ll, lane < 32 ? 5u : 0u, lane, o)) return false;
                 lz_build_sub(L, lane);
+                fixed_built = true;
             }
         }
         const bool last = inf.last_block;
@@ -335,13 +345,22 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
 #endif
     return true;
 }
-__global__ __launch_bounds__(kWave, 2) void inflate_lz_kernel(InflateBatchArgs a) {
+#ifndef FDH_LZ_WAVES_PER_EU
+#define FDH_LZ_WAVES_PER_EU ((FDH_LZ_WAVES_PER_CU + 3) / 4)
+#endif
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FDH_LZ_WAVES_PER_EU, FDH_LZ_WAVES_PER_EU)))
+void inflate_lz_kernel(InflateBatchArgs a) {
     __shared__ LzLds lds;
     const uint32_t cnt = a.list[0];
     for (uint32_t i = blockIdx.x; i < cnt;) {
-        lz_one(a, lds, a.list[4 + i]);
+        const uint32_t sid = a.list[4 + i];
+        const bool finished = lz_one(a, lds, sid);
         wave_sync();
-        if (threadIdx.x == 0) i = atomicAdd(a.lz_counter, 1u) + gridDim.x;
+        if (threadIdx.x == 0) {
+            // what this kernel leaves goes on a list of its own: the kernels behind do not look at the rest
+            if (!finished && a.list_out) a.list_out[4 + atomicAdd(&a.list_out[0], 1u)] = sid;
+            i = atomicAdd(a.lz_counter, 1u) + gridDim.x;
+        }
         i = uni(i);
     }
 }
@@ -740,7 +759,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr};
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
         int ordinal = 0;
         if (hipGetDevice(&ordinal) == hipSuccess && ordinal >= 0 && ordinal < 64) {
@@ -862,8 +881,14 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             if (e == hipSuccess && !(flags & 0x1000u)) {  // the LZ-window kernel: persistent wavefronts, FDH_LZ_WAVES_PER_CU per CU
                 a.lz_counter = list + (n + 4) + 2;  // (a spare word of stream_order_kernel's counters, zeroed above)
                 a.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + list_words * sizeof(uint32_t) + ckpt_bytes);
-                hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, stream, a);
-                e = hipGetLastError();
+                // its leftovers: the list region the kernels in front are done with
+                a.list_out = (sa.list == list) ? list + list2_at : list;
+                e = hipMemsetAsync(a.list_out, 0, 4 * sizeof(uint32_t), stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, stream, a);
+                    e = hipGetLastError();
+                }
+                a.list = a.list_out;
             }
             if (e == hipSuccess && (flags & 0x2000u)) {  // debug: what the LZ-window kernel left stays PENDING
                 (void)hipFreeAsync(list, stream);

@@ -31,25 +31,35 @@
 // too small, a wrong checksum) leaves the stream PENDING for the exact kernels behind it.
 #pragma once
 #include "inflate_stream.h"
+#include <type_traits>
 
 namespace fdh {
 
-constexpr int kLzLitBits = 10;
-constexpr uint32_t kLzLitMask = (1u << kLzLitBits) - 1;
+#ifndef FDH_LZ_LIT_BITS
+#define FDH_LZ_LIT_BITS 9
+#endif
+#ifndef FDH_LZ_DIST_BITS
+#define FDH_LZ_DIST_BITS 8
+#endif
+constexpr int kLzLitBits = FDH_LZ_LIT_BITS;    // index bits of the literal/length table (longer codes: second level)
+constexpr int kLzDistBits = FDH_LZ_DIST_BITS;  // index bits of the distance table (longer codes: the slow step)
+constexpr uint32_t kLzLitMask = (1u << kLzLitBits) - 1, kLzDistMask = (1u << kLzDistBits) - 1;
+constexpr int kLzLitLong = 15 - kLzLitBits, kLzDistLong = 15 - kLzDistBits;  // code lengths beyond the indices
+static_assert(kLzLitBits >= 9 && kLzLitBits <= 12 && kLzDistBits >= 7 && kLzDistBits <= 10, "table index bits");
 #ifndef FDH_LZ_RING
-#define FDH_LZ_RING 4608
+#define FDH_LZ_RING 3072
 #endif
 #ifndef FDH_LZ_WAVES_PER_CU
-#define FDH_LZ_WAVES_PER_CU 8
+#define FDH_LZ_WAVES_PER_CU 11
 #endif
 #ifndef FDH_LZ_RANGE
-#define FDH_LZ_RANGE 256
+#define FDH_LZ_RANGE 192
 #endif
 #ifndef FDH_LZ_IMG
-#define FDH_LZ_IMG 3584
+#define FDH_LZ_IMG 2560
 #endif
 #ifndef FDH_LZ_WARM
-#define FDH_LZ_WARM 256
+#define FDH_LZ_WARM 192
 #endif
 constexpr uint32_t kLzRange = FDH_LZ_RANGE;  // stream bits of a lane's range walked per phase (an item of pass 2)
 constexpr uint32_t kLzWarm = FDH_LZ_WARM;    // bits a guessed chain walks in front of its range
@@ -64,22 +74,31 @@ constexpr uint32_t kLzSlotDw = ((31 + kLzRange + 96 + 31) / 32) | 1u;
 constexpr uint32_t kLzStageDw = 64 * kLzSlotDw;
 static_assert(kLzStageDw >= 256, "the far buffer and the header parser borrow the first KiB of the stage");
 constexpr uint32_t kLzIdxCap = kLzImgCap / 4;  // matches of one span (a match is at least three bytes; the bench's zlib-6 streams: one per 5.2)
-static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 1024, "ring = image + history");
+static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 512, "ring = image + history");
 
 struct __attribute__((aligned(16))) LzWork {
     uint32_t stage[kLzStageDw];    // the span's stream bytes (coalesced copy)
     uint16_t idx[kLzIdxCap + 2];   // where the image's matches start, in stream order (+ a spare entry for stores that are not wanted)
 };
-constexpr uint32_t kLzSub = 512;  // second-level entries of the literal/length table (codes of 11 .. 15 bits)
+constexpr uint32_t kLzSub = 512;  // second-level entries of the literal/length table (codes beyond its index)
+// Decode tables of the current block in the walk's entry layout (below), with the canonical bookkeeping the
+// second level and the slow step read.
+struct __attribute__((aligned(16))) LzTables {
+    uint32_t lit[1 << kLzLitBits];
+    uint32_t dist[1 << kLzDistBits];
+    CodeBook lit_cb;
+    CodeBook dist_cb;
+    uint16_t lit_sorted[288];
+    uint16_t dist_sorted[32];
+};
 struct __attribute__((aligned(16))) LzLds {
-    TableSetT<kLzLitBits> tables;  // lit / dist re-encoded for the walk (lz_convert_tables)
+    LzTables tables;
     uint32_t sub[kLzSub];          // second level of tables.lit (lz_build_sub)
     union {
         // block headers are parsed by the wave-serial reader (inflate_stream.h) between spans: it only ever
-        // touches WaveIo::in_ring (its first member) and the header scratch, so that is all it gets
+        // touches WaveIo::in_ring (its first member): the tables are this kernel's own business
         struct {
             uint32_t in_ring[kInRingDw];
-            HeaderScratch hs;
         } hdr;
         LzWork w;
     } u;
@@ -140,37 +159,34 @@ __device__ __forceinline__ uint32_t lz_conv_dist(uint32_t de) {
     }
     return k == D_LONG ? (LZD_SPECIAL | LZD_LONG) : LZD_SPECIAL;
 }
-__device__ __forceinline__ void lz_convert_tables(TableSetT<kLzLitBits>& T, int lane) {
-    wave_sync();
-    // (not unrolled / vectorised: hipcc 7.2 crashes in instruction selection on the unrolled form)
-#pragma clang loop vectorize(disable) unroll(disable)
-    for (int i = lane; i < (1 << kLzLitBits); i += kWave) T.lit[i] = lz_conv_lit(T.lit[i]);
-#pragma clang loop vectorize(disable) unroll(disable)
-    for (int i = lane; i < kDistSize; i += kWave) T.dist[i] = lz_conv_dist(T.dist[i]);
-    wave_sync();
-}
-
 // Second level of the literal/length table (the reference's secondary tables, src/huffman.rs:138-181, in
 // this kernel's entry layout): every 10-bit prefix that longer codes share gets 2^(longest - 10) entries
 // of LzLds::sub.  Prefixes that do not fit keep the canonical-walk marker.
 // Call after lz_convert_tables; CodeBook / sorted symbols as build_table left them.
 __device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
-    TableSetT<kLzLitBits>& T = L.tables;
+    LzTables& T = L.tables;
     const CodeBook& cb = T.lit_cb;
-    uint32_t nsyms = 0, offs[5], first[5];
+    constexpr int NL = kLzLitLong;  // lengths kLzLitBits + 1 .. 15
+    uint32_t nsyms = 0, offs[NL], first[NL];
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-        offs[i] = uni(cb.offs[11 + i]);
-        first[i] = uni(cb.first[11 + i]);
+    for (int i = 0; i < NL; i++) {
+        offs[i] = uni(cb.offs[kLzLitBits + 1 + i]);
+        first[i] = uni(cb.first[kLzLitBits + 1 + i]);
     }
-    nsyms = offs[4] + uni(cb.hist[15]);
+    nsyms = offs[NL - 1] + uni(cb.hist[15]);
     if (nsyms == offs[0]) return;  // no code beyond the index
-    constexpr uint32_t kWalk = LZW_SPECIAL | (1u << 28);  // what lz_convert_tables left in the shared prefixes
+    constexpr uint32_t kWalk = LZW_SPECIAL | (1u << 28);  // what the table fill left in the shared prefixes
     auto code_of = [&](uint32_t j, uint32_t& l, uint32_t& rev) __attribute__((always_inline)) {
-        const uint32_t li = (j >= offs[1] ? 1u : 0u) + (j >= offs[2] ? 1u : 0u) + (j >= offs[3] ? 1u : 0u) + (j >= offs[4] ? 1u : 0u);
-        const uint32_t o = li == 0 ? offs[0] : li == 1 ? offs[1] : li == 2 ? offs[2] : li == 3 ? offs[3] : offs[4];
-        const uint32_t f = li == 0 ? first[0] : li == 1 ? first[1] : li == 2 ? first[2] : li == 3 ? first[3] : first[4];
-        l = 11 + li;
+        uint32_t li = 0;
+#pragma unroll
+        for (int i = 1; i < NL; i++) li += j >= offs[i] ? 1u : 0u;
+        uint32_t o = offs[0], f = first[0];
+#pragma unroll
+        for (int i = 1; i < NL; i++) {  // (vsel: hipcc turns a plain chain of selects into a table in scratch memory)
+            o = vsel(li == (uint32_t)i, offs[i], o);
+            f = vsel(li == (uint32_t)i, first[i], f);
+        }
+        l = kLzLitBits + 1 + li;
         rev = __brev(f + (j - o)) >> (32 - l);
     };
     // the longest code of every prefix, kept in the prefix's own entry: marker | length
@@ -180,11 +196,12 @@ __device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
         atomicMax(&T.lit[rev & kLzLitMask], kWalk | l);
     }
     wave_sync();
-    {   // allocation: lane i owns the prefixes 16 i .. 16 i + 15
-        uint32_t sz[16], tot = 0;
+    {   // allocation: lane i owns the prefixes PER i .. PER i + PER - 1
+        constexpr int PER = (1 << kLzLitBits) / kWave;
+        uint32_t sz[PER], tot = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t e = T.lit[16 * lane + i];
+        for (int i = 0; i < PER; i++) {
+            const uint32_t e = T.lit[PER * lane + i];
             const uint32_t m = (e & 0xFFFFFFE0u) == kWalk ? (e & 31) : 0u;
             sz[i] = m ? 1u << (m - kLzLitBits) : 0u;
             tot += sz[i];
@@ -197,10 +214,10 @@ __device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
         }
         uint32_t off = incl - tot;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < PER; i++) {
             if (sz[i]) {
-                const uint32_t m = T.lit[16 * lane + i] & 31;
-                T.lit[16 * lane + i] = off + sz[i] <= kLzSub ? (LZW_TWO | (off << 8) | (m - kLzLitBits)) : kWalk;
+                const uint32_t m = T.lit[PER * lane + i] & 31;
+                T.lit[PER * lane + i] = off + sz[i] <= kLzSub ? (LZW_TWO | (off << 8) | (m - kLzLitBits)) : kWalk;
                 off += sz[i];
             }
         }
@@ -228,21 +245,21 @@ struct LzTok {
 // Bounds of the canonical codes beyond the primary tables (CodeBook::run after build_table: the
 // left-justified 16-bit bound of the codes of length <= l), uniform per block: kept in scalar registers.
 struct LzBounds {
-    uint32_t lit[5];   // lengths 11 .. 15
-    uint32_t dist[6];  // lengths 10 .. 15
+    uint32_t lit[kLzLitLong];    // lengths kLzLitBits + 1 .. 15
+    uint32_t dist[kLzDistLong];  // lengths kLzDistBits + 1 .. 15
 };
-__device__ __forceinline__ LzBounds lz_load_bounds(const TableSetT<kLzLitBits>& T) {
+__device__ __forceinline__ LzBounds lz_load_bounds(const LzTables& T) {
     LzBounds b;
 #pragma unroll
-    for (int i = 0; i < 5; i++) b.lit[i] = uni(T.lit_cb.run[11 + i]);
+    for (int i = 0; i < kLzLitLong; i++) b.lit[i] = uni(T.lit_cb.run[kLzLitBits + 1 + i]);
 #pragma unroll
-    for (int i = 0; i < 6; i++) b.dist[i] = uni(T.dist_cb.run[10 + i]);
+    for (int i = 0; i < kLzDistLong; i++) b.dist[i] = uni(T.dist_cb.run[kLzDistBits + 1 + i]);
     return b;
 }
 
 // The token in front of (hi:lo), every case: codes beyond the primary tables are resolved against the
 // canonical bounds (long_walk of inflate_tables.h with the bounds in registers).
-__device__ __forceinline__ LzTok lz_token_slow(const TableSetT<kLzLitBits>& T, const uint32_t* sub, const LzBounds& bd, uint32_t lo, uint32_t hi) {
+__device__ __forceinline__ LzTok lz_token_slow(const LzTables& T, const uint32_t* sub, const LzBounds& bd, uint32_t lo, uint32_t hi) {
     LzTok t;
     t.kind = 3;
     t.bits = t.n = t.v = 0;
@@ -250,10 +267,10 @@ __device__ __forceinline__ LzTok lz_token_slow(const TableSetT<kLzLitBits>& T, c
     if ((e & LZW_TWO) == LZW_TWO) e = sub[((e >> 8) & 0xFFFFF) + __builtin_amdgcn_ubfe(lo, kLzLitBits, e & 31)];
     if ((e & LZW_SPECIAL) && ((e >> 28) & 3) == 1) {
         const uint32_t r16 = __brev(lo) >> 16;
-        uint32_t len = 11;
+        uint32_t len = kLzLitBits + 1;
 #pragma unroll
-        for (int i = 0; i < 4; i++) len += r16 >= bd.lit[i] ? 1u : 0u;
-        if (r16 >= bd.lit[4]) return t;
+        for (int i = 0; i < kLzLitLong - 1; i++) len += r16 >= bd.lit[i] ? 1u : 0u;
+        if (r16 >= bd.lit[kLzLitLong - 1]) return t;
         const uint32_t d = (r16 >> (16 - len)) - T.lit_cb.first[len];
         const uint32_t sym = T.lit_sorted[T.lit_cb.offs[len] + d];
         e = lz_conv_lit(LitlenTraitsT<kLzLitBits>::entry(sym, len));
@@ -275,14 +292,14 @@ __device__ __forceinline__ LzTok lz_token_slow(const TableSetT<kLzLitBits>& T, c
     const uint32_t tb = e & 31, ex = (e >> 5) & 7, nb = (e >> 8) & 15;
     const uint32_t length = ((e >> 16) & 0x1FF) + __builtin_amdgcn_ubfe(lo, nb, ex);
     const uint32_t dv = __builtin_amdgcn_alignbit(hi, lo, tb);
-    uint32_t de = T.dist[dv & (kDistSize - 1)];
+    uint32_t de = T.dist[dv & kLzDistMask];
     if (de & LZD_SPECIAL) {
         if (!(de & LZD_LONG)) return t;
         const uint32_t r16 = __brev(dv) >> 16;
-        uint32_t len = 10;
+        uint32_t len = kLzDistBits + 1;
 #pragma unroll
-        for (int i = 0; i < 5; i++) len += r16 >= bd.dist[i] ? 1u : 0u;
-        if (r16 >= bd.dist[5]) return t;
+        for (int i = 0; i < kLzDistLong - 1; i++) len += r16 >= bd.dist[i] ? 1u : 0u;
+        if (r16 >= bd.dist[kLzDistLong - 1]) return t;
         const uint32_t d = (r16 >> (16 - len)) - T.dist_cb.first[len];
         const uint32_t sym = T.dist_sorted[T.dist_cb.offs[len] + d];
         de = lz_conv_dist(DistTraits::entry(sym, len));
@@ -318,7 +335,7 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
                                           const bool active, const uint32_t limit, const uint32_t slot_dw, uint32_t q_rel,
                                           const uint32_t o_ri, const uint32_t o_abs, uint32_t mi, bool& trouble, uint32_t* iters = nullptr,
                                           uint32_t* slows = nullptr) {
-    const TableSetT<kLzLitBits>& T = L.tables;
+    const LzTables& T = L.tables;
     LzWalk w;
     uint32_t cnt = 0, nm = 0, stop = 0, stop_bits = 0;
     bool run = active && pos < end;
@@ -344,7 +361,7 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
             const bool is_len = (int32_t)e < 0;
             const uint32_t length = ((e >> 16) & 0x1FF) + __builtin_amdgcn_ubfe(lo, (e >> 8) & 15, (e >> 5) & 7);
             const uint32_t dv = __builtin_amdgcn_alignbit(hi, lo, tb);
-            const uint32_t de = T.dist[dv & (kDistSize - 1)];
+            const uint32_t de = T.dist[dv & kLzDistMask];
             special = (e & LZW_SPECIAL) != 0 || (is_len && (de & LZD_SPECIAL) != 0);
             const uint32_t bits = tb + (is_len ? (de & 31) : 0u);
             const uint32_t inc = is_len ? length : ((e >> 5) & 3);
@@ -478,6 +495,7 @@ __device__ __forceinline__ uint32_t lz_stage_slot(LzLds& L, const bool active, c
                 v[2] = q.z;
                 v[3] = q.w;
             } else {
+#pragma unroll
                 for (int j = 0; j < 16; j++) {
                     if (w0 + j < win_bytes && p + j >= buf_lo && p + j < buf_hi) v[j >> 2] |= (uint32_t)p[j] << (8 * (j & 3));
                 }
@@ -488,6 +506,134 @@ __device__ __forceinline__ uint32_t lz_stage_slot(LzLds& L, const bool active, c
         }
     }
     return dw;
+}
+
+// Builds the walk tables, the canonical bookkeeping (and nothing else) from the code lengths: ll[k] = length
+// of literal/length symbol lane + 64 k, dl = length of distance symbol `lane`.  false unless the codes are
+// what the reference accepts (src/decompress.rs:561-606: complete, or no / one distance code).
+template <class OUT>
+__device__ __forceinline__ bool lz_build_tables(LzLds& L, const uint32_t (&ll)[5], const uint32_t dl, const int lane, OUT& o) {
+    LzTables& T = L.tables;
+    auto rank_in = [&](uint64_t m) __attribute__((always_inline)) -> uint32_t {  // lanes of m below this one
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    // ---- canonical bookkeeping of a code: lengths ranked with ballots ----
+    // sym_len(k): length of symbol lane + 64 k.  Writes sorted[], the CodeBook; returns false unless complete.
+    auto canon = [&](auto&& sym_len, auto rounds_c, CodeBook& cb, uint16_t* sorted, uint32_t (&bound)[16], uint32_t& nsyms,
+                     uint32_t& maxlen) __attribute__((always_inline)) -> bool {
+        constexpr int rounds = decltype(rounds_c)::value;
+        uint32_t hist[16], first[16], offs[16];
+        hist[0] = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            uint32_t n = 0;
+#pragma unroll
+            for (int k = 0; k < rounds; k++) n += (uint32_t)__popcll(__ballot(sym_len(k) == l));
+            hist[l] = n;
+        }
+        uint32_t kraft = 0, code = 0, off = 0;
+        nsyms = 0;
+        maxlen = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            kraft += hist[l] << (15 - l);
+            code = (code + hist[l - 1]) << 1;
+            first[l] = code;
+            offs[l] = off;
+            off += hist[l];
+            bound[l] = (code + hist[l]) << (16 - l);
+            if (hist[l]) maxlen = l;
+        }
+        nsyms = off;
+        // (lane l keeps the books the slow path and the second level read)
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            if (lane == (int)l) {
+                cb.hist[l] = hist[l];
+                cb.first[l] = first[l];
+                cb.offs[l] = offs[l];
+                cb.run[l] = bound[l];
+            }
+        }
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            uint32_t seen = 0;
+#pragma unroll
+            for (int k = 0; k < rounds; k++) {
+                const uint64_t m = __ballot(sym_len(k) == l);
+                if (sym_len(k) == l) sorted[offs[l] + seen + rank_in(m)] = (uint16_t)(lane + 64 * k);
+                seen += (uint32_t)__popcll(m);
+            }
+        }
+        return kraft == (1u << 15);
+    };
+    uint32_t lb[16], db[16], ln, lmax, dn, dmax;
+    const bool lit_ok = canon([&](int k) { return ll[k]; }, std::integral_constant<int, 5>{}, T.lit_cb, T.lit_sorted, lb, ln, lmax);
+    if (!lit_ok) return false;  // src/decompress.rs:570-580
+    const bool dist_ok = canon([&](int) { return dl; }, std::integral_constant<int, 1>{}, T.dist_cb, T.dist_sorted, db, dn, dmax);
+    const bool dist_none = dn == 0, dist_one = dn == 1 && dmax == 1;  // src/decompress.rs:588-589, src/huffman.rs:45-58
+    if (!dist_ok && !dist_none && !dist_one) return false;
+    wave_sync();
+    LZT(o, 15);
+
+    // ---- every table index decodes itself ----
+    auto decode = [&](const uint32_t r16, const uint32_t (&bound)[16], const int maxbits, const CodeBook& cb, const uint16_t* sorted,
+                      uint32_t& len) __attribute__((always_inline)) -> uint32_t {
+        len = 1;
+#pragma unroll
+        for (int l = 1; l < 15; l++)
+            if (l < maxbits) len += r16 >= bound[l] ? 1u : 0u;
+        if (r16 >= bound[maxbits]) {  // a code longer than the index
+            len = 0;
+            return 0;
+        }
+        return sorted[cb.offs[len] + (r16 >> (16 - len)) - cb.first[len]];
+    };
+    auto lit_entry = [&](const uint32_t sym, const uint32_t len) __attribute__((always_inline)) -> uint32_t {
+        if (sym < 256) return len | (1u << 5) | (sym << 8);
+        if (sym == 256 || sym >= 286) return LZW_SPECIAL | len;  // 286 / 287: reference src/tables.rs:100
+        const uint32_t eb = len_extra_base(sym - 257), ex = eb & 0xFF, base = eb >> 8;
+        return LZW_LEN | (len + ex) | (ex << 5) | (len << 8) | (base << 16);
+    };
+    for (int it = 0; it < (1 << kLzLitBits) / kWave; it++) {
+        const uint32_t idx = (uint32_t)lane + 64u * it;
+        uint32_t len;
+        const uint32_t sym = decode(__brev(idx) >> 16, lb, kLzLitBits, T.lit_cb, T.lit_sorted, len);
+        uint32_t e = LZW_SPECIAL | (1u << 28);  // code beyond the index: canonical walk unless the second level takes it
+        if (len) {
+            e = lit_entry(sym, len);
+            if (sym < 256 && len < (uint32_t)kLzLitBits) {  // a second literal whose code fits the index as well
+                uint32_t len2;
+                const uint32_t sym2 = decode(__brev(idx >> len) >> 16, lb, kLzLitBits, T.lit_cb, T.lit_sorted, len2);
+                if (len2 && sym2 < 256 && len + len2 <= (uint32_t)kLzLitBits) e = (len + len2) | (2u << 5) | (sym << 8) | (sym2 << 16);
+            }
+        }
+        T.lit[idx] = e;
+    }
+    for (int it = 0; it < (1 << kLzDistBits) / kWave; it++) {
+        const uint32_t idx = (uint32_t)lane + 64u * it;
+        uint32_t e = LZD_SPECIAL;
+        if (dist_one) {  // one 1-bit code: '0' is that symbol, '1' is invalid
+            const uint32_t sym = T.dist_sorted[0];
+            if (!(idx & 1) && sym < 30) {
+                const uint32_t eb = dist_extra_base(sym), ex = eb & 0xFF;
+                e = (1 + ex) | (1u << 5) | (ex << 9) | ((eb >> 8) << 16);
+            }
+        } else if (!dist_none) {
+            uint32_t len;
+            const uint32_t sym = decode(__brev(idx) >> 16, db, kLzDistBits, T.dist_cb, T.dist_sorted, len);
+            if (len == 0) {
+                e = LZD_SPECIAL | LZD_LONG;
+            } else if (sym < 30) {
+                const uint32_t eb = dist_extra_base(sym), ex = eb & 0xFF;
+                e = (len + ex) | (len << 5) | (ex << 9) | ((eb >> 8) << 16);
+            }
+        }
+        T.dist[idx] = e;
+    }
+    wave_sync();
+    LZT(o, 16);
+    return true;
 }
 
 // ---- dynamic block header, this kernel's own: code-length code in registers, tables filled by index ----
@@ -503,7 +649,7 @@ __device__ __forceinline__ uint32_t lz_stage_slot(LzLds& L, const bool active, c
 template <class INF, class OUT>
 __device__ __forceinline__ bool lz_parse_dynamic(LzLds& L, INF& inf, const uint32_t hlit, const uint32_t hdist, const uint32_t hclen,
                                                  const int lane, OUT& o) {
-    TableSetT<kLzLitBits>& T = L.tables;
+    LzTables& T = L.tables;
     const uint32_t lt_lo = (uint32_t)lanemask_lt(lane), lt_hi = (uint32_t)(lanemask_lt(lane) >> 32);
     auto rank_in = [&](uint64_t m) __attribute__((always_inline)) -> uint32_t {  // lanes of m below this one
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -612,53 +758,6 @@ __device__ __forceinline__ bool lz_parse_dynamic(LzLds& L, INF& inf, const uint3
     LZT(o, 14);
     if (__builtin_amdgcn_readlane(Ln[4], 0) == 0) return false;  // no end-of-block code (src/decompress.rs:563-566)
 
-    // ---- canonical bookkeeping of a code: lengths ranked with ballots ----
-    // sym_len(k): length of symbol lane + 64 k.  Writes sorted[], the CodeBook; returns false unless complete.
-    auto canon = [&](auto&& sym_len, const int rounds, CodeBook& cb, uint16_t* sorted, uint32_t (&bound)[16], uint32_t& nsyms,
-                     uint32_t& maxlen) __attribute__((always_inline)) -> bool {
-        uint32_t hist[16], first[16], offs[16];
-        hist[0] = 0;
-#pragma unroll
-        for (uint32_t l = 1; l <= 15; l++) {
-            uint32_t n = 0;
-            for (int k = 0; k < rounds; k++) n += (uint32_t)__popcll(__ballot(sym_len(k) == l));
-            hist[l] = n;
-        }
-        uint32_t kraft = 0, code = 0, off = 0;
-        nsyms = 0;
-        maxlen = 0;
-#pragma unroll
-        for (uint32_t l = 1; l <= 15; l++) {
-            kraft += hist[l] << (15 - l);
-            code = (code + hist[l - 1]) << 1;
-            first[l] = code;
-            offs[l] = off;
-            off += hist[l];
-            bound[l] = (code + hist[l]) << (16 - l);
-            if (hist[l]) maxlen = l;
-        }
-        nsyms = off;
-        // (lane l keeps the books the slow path and the second level read)
-#pragma unroll
-        for (uint32_t l = 1; l <= 15; l++) {
-            if (lane == (int)l) {
-                cb.hist[l] = hist[l];
-                cb.first[l] = first[l];
-                cb.offs[l] = offs[l];
-                cb.run[l] = bound[l];
-            }
-        }
-#pragma unroll
-        for (uint32_t l = 1; l <= 15; l++) {
-            uint32_t seen = 0;
-            for (int k = 0; k < rounds; k++) {
-                const uint64_t m = __ballot(sym_len(k) == l);
-                if (sym_len(k) == l) sorted[offs[l] + seen + rank_in(m)] = (uint16_t)(lane + 64 * k);
-                seen += (uint32_t)__popcll(m);
-            }
-        }
-        return kraft == (1u << 15);
-    };
     uint32_t ll[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) ll[k] = (uint32_t)lane + 64u * k < hlit ? Ln[k] : 0u;
@@ -670,73 +769,7 @@ __device__ __forceinline__ bool lz_parse_dynamic(LzLds& L, INF& inf, const uint3
         dl = ((uint32_t)lane < hdist && (at >> 6) == 4) ? v : 0u;
         if (hlit + hdist > 320) return false;  // cannot happen (286 + 30)
     }
-    uint32_t lb[16], db[16], ln, lmax, dn, dmax;
-    const bool lit_ok = canon([&](int k) { return ll[k]; }, 5, T.lit_cb, T.lit_sorted, lb, ln, lmax);
-    if (!lit_ok) return false;  // src/decompress.rs:570-580
-    const bool dist_ok = canon([&](int) { return dl; }, 1, T.dist_cb, T.dist_sorted, db, dn, dmax);
-    const bool dist_none = dn == 0, dist_one = dn == 1 && dmax == 1;  // src/decompress.rs:588-589, src/huffman.rs:45-58
-    if (!dist_ok && !dist_none && !dist_one) return false;
-    wave_sync();
-    LZT(o, 15);
-
-    // ---- every table index decodes itself ----
-    auto decode = [&](const uint32_t r16, const uint32_t (&bound)[16], const int maxbits, const CodeBook& cb, const uint16_t* sorted,
-                      uint32_t& len) __attribute__((always_inline)) -> uint32_t {
-        len = 1;
-#pragma unroll
-        for (int l = 1; l < 15; l++)
-            if (l < maxbits) len += r16 >= bound[l] ? 1u : 0u;
-        if (r16 >= bound[maxbits]) {  // a code longer than the index
-            len = 0;
-            return 0;
-        }
-        return sorted[cb.offs[len] + (r16 >> (16 - len)) - cb.first[len]];
-    };
-    auto lit_entry = [&](const uint32_t sym, const uint32_t len) __attribute__((always_inline)) -> uint32_t {
-        if (sym < 256) return len | (1u << 5) | (sym << 8);
-        if (sym == 256 || sym >= 286) return LZW_SPECIAL | len;  // 286 / 287: reference src/tables.rs:100
-        const uint32_t eb = len_extra_base(sym - 257), ex = eb & 0xFF, base = eb >> 8;
-        return LZW_LEN | (len + ex) | (ex << 5) | (len << 8) | (base << 16);
-    };
-    for (int it = 0; it < (1 << kLzLitBits) / kWave; it++) {
-        const uint32_t idx = (uint32_t)lane + 64u * it;
-        uint32_t len;
-        const uint32_t sym = decode(__brev(idx) >> 16, lb, kLzLitBits, T.lit_cb, T.lit_sorted, len);
-        uint32_t e = LZW_SPECIAL | (1u << 28);  // code beyond the index: canonical walk unless the second level takes it
-        if (len) {
-            e = lit_entry(sym, len);
-            if (sym < 256 && len < (uint32_t)kLzLitBits) {  // a second literal whose code fits the index as well
-                uint32_t len2;
-                const uint32_t sym2 = decode(__brev(idx >> len) >> 16, lb, kLzLitBits, T.lit_cb, T.lit_sorted, len2);
-                if (len2 && sym2 < 256 && len + len2 <= (uint32_t)kLzLitBits) e = (len + len2) | (2u << 5) | (sym << 8) | (sym2 << 16);
-            }
-        }
-        T.lit[idx] = e;
-    }
-    for (int it = 0; it < kDistSize / kWave; it++) {
-        const uint32_t idx = (uint32_t)lane + 64u * it;
-        uint32_t e = LZD_SPECIAL;
-        if (dist_one) {  // one 1-bit code: '0' is that symbol, '1' is invalid
-            const uint32_t sym = T.dist_sorted[0];
-            if (!(idx & 1) && sym < 30) {
-                const uint32_t eb = dist_extra_base(sym), ex = eb & 0xFF;
-                e = (1 + ex) | (1u << 5) | (ex << 9) | ((eb >> 8) << 16);
-            }
-        } else if (!dist_none) {
-            uint32_t len;
-            const uint32_t sym = decode(__brev(idx) >> 16, db, kDistBits, T.dist_cb, T.dist_sorted, len);
-            if (len == 0) {
-                e = LZD_SPECIAL | LZD_LONG;
-            } else if (sym < 30) {
-                const uint32_t eb = dist_extra_base(sym), ex = eb & 0xFF;
-                e = (len + ex) | (len << 5) | (ex << 9) | ((eb >> 8) << 16);
-            }
-        }
-        T.dist[idx] = e;
-    }
-    wave_sync();
-    LZT(o, 16);
-    return true;
+    return lz_build_tables(L, ll, dl, lane, o);
 }
 
 struct LzOut {
