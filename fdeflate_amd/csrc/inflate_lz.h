@@ -328,8 +328,8 @@ struct LzWalk {
 // its first match in the image's list.  `trouble` collects what must never happen on a real chain.
 //
 // The fast step is branch-free and the same for every lane: a lane in front of a special token (a code
-// beyond the tables, end-of-block, an impossible token) simply does not advance; every fourth step, or
-// when nobody else moves, those lanes take the slow step, which knows every case.
+// beyond the tables, end-of-block, an impossible token) simply does not advance; behind every fourth
+// step those lanes take the slow step, which knows every case.
 template <bool EMIT>
 __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t pos, const uint32_t end, const bool slide,
                                           const bool active, const uint32_t limit, const uint32_t slot_dw, uint32_t q_rel,
@@ -344,25 +344,32 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
     const uint32_t* const slot = &L.u.w.stage[kLzSlotDw * (threadIdx.x & 63)];
     const uint32_t bit0 = slot_dw * 32;
     while (__any(run)) {
-        if (++it > 8192) {  // cannot happen; never hang
+        it += 4;
+        if (it > 8192) {  // cannot happen; never hang
             trouble = true;
             break;
         }
-        bool special;
-        {
+        bool special = false;
+        // four fast steps without a branch between them (the scalar unit is shared by the CU's wavefronts: loop
+        // control and execution-mask work per step is what eleven of them queue for); a lane that is done or
+        // stands in front of a special token does not move
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
             const uint32_t rel = run ? pos - bit0 : 0u, di = rel >> 5, sh = rel & 31;
             const uint32_t r0 = slot[di], r1 = slot[di + 1], r2 = slot[di + 2];
             const uint32_t lo = __builtin_amdgcn_alignbit(r1, r0, sh), hi = __builtin_amdgcn_alignbit(r2, r1, sh);
             uint32_t e = T.lit[lo & kLzLitMask];
-            if (__any((e & LZW_TWO) == LZW_TWO)) {  // a code of 11 .. 15 bits: its second-level entry
-                if ((e & LZW_TWO) == LZW_TWO) e = L.sub[((e >> 8) & 0xFFFFF) + __builtin_amdgcn_ubfe(lo, kLzLitBits, e & 31)];
+            {   // a code beyond the index: its second-level entry (every lane looks one up: no branch)
+                const bool two = (e & LZW_TWO) == LZW_TWO;
+                const uint32_t e2 = L.sub[two ? ((e >> 8) & 0xFFFFF) + __builtin_amdgcn_ubfe(lo, kLzLitBits, e & 31) : 0u];
+                e = two ? e2 : e;
             }
             const uint32_t tb = e & 31;
             const bool is_len = (int32_t)e < 0;
             const uint32_t length = ((e >> 16) & 0x1FF) + __builtin_amdgcn_ubfe(lo, (e >> 8) & 15, (e >> 5) & 7);
             const uint32_t dv = __builtin_amdgcn_alignbit(hi, lo, tb);
             const uint32_t de = T.dist[dv & kLzDistMask];
-            special = (e & LZW_SPECIAL) != 0 || (is_len && (de & LZD_SPECIAL) != 0);
+            special = (e & LZW_SPECIAL) != 0 || (is_len && (de & LZD_SPECIAL) != 0);  // (of the last step: what the slow step looks at)
             const uint32_t bits = tb + (is_len ? (de & 31) : 0u);
             const uint32_t inc = is_len ? length : ((e >> 5) & 3);
             const bool go = run && !special;
@@ -388,7 +395,7 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
             pos += go ? bits : 0u;
             run = run && pos < end;
         }
-        if ((it & 3) == 0 || !__any(run && !special)) {
+        {
             const bool act = run && special;
             if (__any(act)) {
                 const uint32_t rel = act ? pos - bit0 : 0u, di = rel >> 5, sh = rel & 31;

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-FDH_LIB=$PWD/fdeflate_amd/libfdeflate_hip_lz_c.so rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lzc -- python3 tools/gendiag.py 65536 0 > gpurun_out/prof_lzc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lzc -- python3 tools/gendiag.py 65536 0 > gpurun_out/prof_lzc.log 2>&1
 python3 - <<'PY'
 import csv,glob
 for f in glob.glob("gpurun_out/prof_lzc/**/*kernel_stats.csv", recursive=True):
