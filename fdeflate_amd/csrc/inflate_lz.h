@@ -64,6 +64,10 @@ static_assert(kLzLitBits >= 9 && kLzLitBits <= 12 && kLzDistBits >= 7 && kLzDist
 constexpr uint32_t kLzRange = FDH_LZ_RANGE;  // stream bits of a lane's range walked per phase (an item of pass 2)
 constexpr uint32_t kLzWarm = FDH_LZ_WARM;    // bits a guessed chain walks in front of its range
 constexpr uint32_t kLzImgCap = FDH_LZ_IMG;   // output bytes resolved at a time (an image)
+#ifndef FDH_LZ_UNROLL
+#define FDH_LZ_UNROLL 4
+#endif
+constexpr int kLzUnroll = FDH_LZ_UNROLL;       // fast steps per loop trip of a walk
 constexpr int kLzMaxPhases = 16;             // phases of a super-span: a lane's range is at most 16 x kLzRange bits
 static_assert(kLzWarm <= kLzRange, "the warm-up walk uses a lane's stage slot like a phase");
 constexpr uint32_t kLzRing = FDH_LZ_RING;   // history + image, a multiple of 64
@@ -344,7 +348,7 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
     const uint32_t* const slot = &L.u.w.stage[kLzSlotDw * (threadIdx.x & 63)];
     const uint32_t bit0 = slot_dw * 32;
     while (__any(run)) {
-        it += 4;
+        it += kLzUnroll;
         if (it > 8192) {  // cannot happen; never hang
             trouble = true;
             break;
@@ -354,7 +358,7 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
         // control and execution-mask work per step is what eleven of them queue for); a lane that is done or
         // stands in front of a special token does not move
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kLzUnroll; u++) {
             const uint32_t rel = run ? pos - bit0 : 0u, di = rel >> 5, sh = rel & 31;
             const uint32_t r0 = slot[di], r1 = slot[di + 1], r2 = slot[di + 2];
             const uint32_t lo = __builtin_amdgcn_alignbit(r1, r0, sh), hi = __builtin_amdgcn_alignbit(r2, r1, sh);
@@ -733,49 +737,104 @@ __device__ __forceinline__ bool lz_parse_dynamic(LzLds& L, INF& inf, const uint3
         }
     }
     LZT(o, 13);
-    // ---- the literal/length + distance code lengths: one chain of bits, a scalar loop ----
-    // the length of symbol n lives in lane n mod 64 of Ln[n / 64]
+    // ---- the literal/length + distance code lengths: one chain of bits ----
+    // 64 bit positions at a time.  Lane p decodes the code-length token that WOULD start at position p of the
+    // window (the table look-up is a lane permutation: no memory); a scalar loop follows the real chain from
+    // token to token -- a readlane and a handful of scalar instructions each -- and marks its lanes; those lanes
+    // then write their lengths to an array in LDS side by side (offsets and the value a "repeat previous"
+    // stands for by prefix scans).  The first version of this parser did everything in the scalar loop: ~500
+    // clocks per token, a third of them waiting for the scalar unit the CU's wavefronts share.
     const uint32_t total = hlit + hdist;
-    uint32_t Ln[5] = {0, 0, 0, 0, 0};
+    uint8_t* const lens = reinterpret_cast<uint8_t*>(&L.u.w.stage[256]);  // 320 code lengths, behind the staged KiB
+    for (int i = lane; i < 80; i += kWave) L.u.w.stage[256 + i] = 0;
+    wave_sync();
     uint32_t nread = 0, prevlen = 0;
+    uint32_t lp = (wbit - c0 * 32) + used;  // the next unread bit, relative to the staged KiB
+    bool bad = false;
     while (nread < total) {
-        refill();
-        const uint32_t idx = (uint32_t)buf & 127;
-        const uint32_t e0 = __builtin_amdgcn_readlane(t_lo, idx & 63), e1 = __builtin_amdgcn_readlane(t_hi, idx & 63);
-        const uint32_t e = idx & 64 ? e1 : e0;
-        const uint32_t sym = e & 0xFF, nb = e >> 8;
-        if (nb == 0) return false;
-        uint32_t rep = 1, value = sym, bits = nb;
-        if (sym > 15) {
-            const uint32_t extra = sym == 16 ? 2u : sym == 17 ? 3u : 7u, base_rep = sym == 18 ? 11u : 3u;
-            if (sym == 16 && nread == 0) return false;
-            value = sym == 16 ? prevlen : 0u;
-            rep = (((uint32_t)buf >> nb) & ((1u << extra) - 1)) + base_rep;
-            bits = nb + extra;
-            if (nread + rep > total) return false;
+        if (lp + 192 > 8192) return false;  // cannot happen: a header is at most 57 + 316 x 14 bits
+        const uint32_t d0 = lp >> 5, off = (lp & 31) + (uint32_t)lane;  // this lane's token starts `off` bits into word d0
+        const uint32_t x0 = word(d0), x1 = word(d0 + 1), x2 = word(d0 + 2), x3 = word(d0 + 3);
+        const uint32_t sel = off >> 5;
+        const uint32_t lo = sel == 0 ? x0 : (sel == 1 ? x1 : x2), hi = sel == 0 ? x1 : (sel == 1 ? x2 : x3);
+        const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, off & 31);
+        const uint32_t idx = v & 127;
+        const uint32_t ea = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63) << 2), (int)t_lo);
+        const uint32_t eb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63) << 2), (int)t_hi);
+        const uint32_t en = idx & 64 ? eb : ea;
+        const uint32_t sym = en & 0xFF, nb = en >> 8;
+        const uint32_t extra = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+        const uint32_t rep = sym <= 15 ? 1u : (sym == 18 ? 11u : 3u) + __builtin_amdgcn_ubfe(v, nb, extra);
+        const uint32_t tokv = nb == 0 ? 0u : ((nb + extra) | (rep << 8));
+        // the chain: which lanes' tokens are real, how many lengths they stand for
+        uint64_t chain = 0;
+        uint32_t pp = 0, nr = nread;
+        while (pp < 64 && nr < total) {
+            const uint32_t tok = __builtin_amdgcn_readlane(tokv, pp);
+            if ((tok & 0xFF) == 0) {
+                bad = true;
+                break;
+            }
+            chain |= 1ull << pp;
+            nr += tok >> 8;
+            pp += tok & 0xFF;
         }
+        if (bad || nr > total) return false;  // an impossible code / a repeat beyond the last length
+        const bool on = (chain >> lane) & 1;
+        // where a lane's lengths go: exclusive prefix sum of the repeat counts along the chain
+        uint32_t incl = on ? rep : 0u;
 #pragma unroll
-        for (int k = 0; k < 5; k++) Ln[k] = ((uint32_t)lane + 64u * k - nread) < rep ? value : Ln[k];
-        prevlen = value;
-        nread += rep;
-        consume(bits);
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, kWave);
+            if (lane >= d) incl += y;
+        }
+        const uint32_t n0 = nread + incl - (on ? rep : 0u);
+        // what "repeat the previous length" repeats: the nearest chain token below that is a length itself
+        // (17 / 18 write zeros, and a 16 behind them repeats that zero)
+        uint32_t key = (on && sym != 16) ? (((uint32_t)lane + 1) << 8) | (sym <= 15 ? sym : 0u) : 0u;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t y = __shfl_up(key, d, kWave);
+            if (lane >= d) key = max(key, y);
+        }
+        const uint32_t value = sym <= 15 ? sym : (sym == 16 ? (key ? (key & 0xFF) : prevlen) : 0u);
+        if (__any(on && sym == 16 && n0 == 0)) return false;  // nothing to repeat (src/decompress.rs:513-529)
+        // short tokens: every lane writes its own (up to four lengths); long repeats: the wavefront, one by one
+        if (on) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (i < rep && rep <= 4) lens[n0 + i] = (uint8_t)value;
+        }
+        uint64_t longm = __ballot(on && rep > 4);
+        while (longm) {
+            const int f = __ffsll((unsigned long long)longm) - 1;
+            longm &= longm - 1;
+            const uint32_t fn0 = __builtin_amdgcn_readlane(n0, f), frep = __builtin_amdgcn_readlane(rep, f), fval = __builtin_amdgcn_readlane(value, f);
+            for (uint32_t i = (uint32_t)lane; i < frep; i += kWave) lens[fn0 + i] = (uint8_t)fval;
+        }
+        // the last chain token's value carries over
+        if (chain) {
+            const int lastl = 63 - __clzll((unsigned long long)chain);
+            prevlen = __builtin_amdgcn_readlane(value, lastl);
+        }
+        nread = nr;
+        lp += pp;
     }
+    used = lp - (wbit - c0 * 32);
     if ((uint64_t)used > inf.left) return false;  // the header runs past the end of the input
     inf.left -= used;
+    wave_sync();
     LZT(o, 14);
-    if (__builtin_amdgcn_readlane(Ln[4], 0) == 0) return false;  // no end-of-block code (src/decompress.rs:563-566)
+    if (lens[256] == 0) return false;  // no end-of-block code (src/decompress.rs:563-566)
 
     uint32_t ll[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) ll[k] = (uint32_t)lane + 64u * k < hlit ? Ln[k] : 0u;
-    uint32_t dl;
-    {   // the distance lengths are the symbols hlit .. hlit + hdist - 1 of the chain: lane i wants symbol hlit + i
-        const uint32_t at = hlit + (uint32_t)lane, ka = hlit >> 6;  // ka = 4 (hlit >= 257): Ln[4], then (never) beyond
-        (void)ka;
-        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((at & 63) << 2), (int)Ln[4]);
-        dl = ((uint32_t)lane < hdist && (at >> 6) == 4) ? v : 0u;
-        if (hlit + hdist > 320) return false;  // cannot happen (286 + 30)
+    for (int k = 0; k < 5; k++) {
+        const uint32_t sy = (uint32_t)lane + 64u * k;
+        ll[k] = sy < hlit ? (uint32_t)lens[sy] : 0u;
     }
+    const uint32_t dl = (uint32_t)lane < hdist ? (uint32_t)lens[hlit + lane] : 0u;
+    wave_sync();
     return lz_build_tables(L, ll, dl, lane, o);
 }
 
