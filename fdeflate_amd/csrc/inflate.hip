@@ -495,28 +495,52 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
 }
 
 // Hand-out order of a batch for persistent wavefronts: the streams of at least half the mean length
-// from the front, the shorter ones from the back (each class roughly in batch order: one atomic per
-// wavefront and class).  A kernel ends when its last long stream does, and while the long streams
-// drain the wavefronts that have run out of work take the short ones instead of idling (the bench
-// batch: every 16th stream 0.5 KB, every 16th half the size).  counters: [0] long, [1] short, zeroed.
-__global__ __launch_bounds__(256) void stream_order_kernel(const uint64_t* in_off, uint32_t n, uint32_t* order, uint32_t* counters) {
+// first (order[0 ..]), then the shorter ones (order[n ..]), each class roughly in batch order (one atomic
+// per wavefront and class).  A kernel ends when its last long stream does, and while the long streams
+// drain the wavefronts that have run out of work take the short ones instead of idling (the bench batch:
+// every 16th stream 0.5 KB, every 16th half the size).  Streams that do not start like an ultra-fast stream
+// (its first eight bytes) never get to the interval kernel: they go straight onto the list of the kernels
+// behind it -- handing 65 536 of them out one atomic at a time only to pass them on cost 0.8 ms.
+// counters: [0] long, [1] short, zeroed.
+__global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, const uint64_t* in_off, uint32_t n, uint32_t* order,
+                                                           uint32_t* counters, const uint32_t* canon_hdr, uint32_t* status,
+                                                           uint32_t pending, uint32_t* list2) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t thr = (in_off[n] - in_off[0]) / n / 2;
     const bool valid = i < n;
-    const bool big = valid && (in_off[i + 1] - in_off[i]) >= thr;
-    const bool small = valid && !big;
-    const uint64_t mb = __ballot(big), ms = __ballot(small);
-    uint32_t base_b = 0, base_s = 0;
+    const uint64_t len = valid ? in_off[i + 1] - in_off[i] : 0;
+    bool canon = valid && len * 8 >= kCanonBits;
+    if (canon) {
+        const uint8_t* p = in + in_off[i];
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            w0 |= (uint32_t)p[j] << (8 * j);
+            w1 |= (uint32_t)p[4 + j] << (8 * j);
+        }
+        canon = w0 == canon_hdr[0] && w1 == canon_hdr[1];
+    }
+    const bool other = valid && !canon;
+    const bool big = canon && len >= thr;
+    const bool small = canon && !big;
+    const uint64_t mb = __ballot(big), ms = __ballot(small), mo = __ballot(other);
+    uint32_t base_b = 0, base_s = 0, base_o = 0;
     if (lane == 0) {
         if (mb) base_b = atomicAdd(&counters[0], (uint32_t)__popcll(mb));
         if (ms) base_s = atomicAdd(&counters[1], (uint32_t)__popcll(ms));
+        if (mo) base_o = atomicAdd(&list2[0], (uint32_t)__popcll(mo));
     }
     base_b = __shfl(base_b, 0);
     base_s = __shfl(base_s, 0);
+    base_o = __shfl(base_o, 0);
     const uint64_t below = (1ull << lane) - 1;
     if (big) order[base_b + (uint32_t)__popcll(mb & below)] = i;
-    if (small) order[n - 1 - (base_s + (uint32_t)__popcll(ms & below))] = i;
+    if (small) order[n + base_s + (uint32_t)__popcll(ms & below)] = i;
+    if (other) {
+        status[i] = pending;
+        list2[4 + base_o + (uint32_t)__popcll(mo & below)] = i;
+    }
 }
 
 // Canonical streams, counted by segments and written by intervals (inflate_seg2.h): one stream per
@@ -538,7 +562,9 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
     // Cache (eight at a time: 3.30 -> 3.38 ms).  An atomic on one address costs ~20 ns when every
     // wavefront is after it -- 1.3 ms for 65 536 streams, all of it exposed in a batch this kernel can
     // only pass on -- so a wavefront that passed on everything it was given takes twice as many next time.
-    const uint32_t n32 = (uint32_t)a.n;
+    // (with a hand-out order: its long streams, then its short ones -- what does not look canonical is not in it)
+    const uint32_t n_long = a.order ? uni(a.order_counts[0]) : 0u;
+    const uint32_t n32 = a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n;
     uint32_t cur = 0, end = 0, take = 1;
     bool took = true;
     for (;;) {
@@ -553,7 +579,7 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
             if (cur >= n32) break;
             end = min(n32, cur + take);
         }
-        took = seg2_decode(a, lds, ckpt, a.order ? uni(a.order[cur]) : cur) || took;
+        took = seg2_decode(a, lds, ckpt, a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur) || took;
         cur++;
     }
 }
@@ -811,7 +837,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         // layout: first list | 4 words: counters of stream_order_kernel | second list | order | checkpoints
         const bool ordered = seg2 && n >= 4ull * s2blocks * fdh::kS2Waves && n <= 0x7FFFFFFFull;
         const size_t list2_at = (size_t)(n + 4) + 4;
-        const size_t list_words = list2_at + (size_t)(n + 4) + (ordered ? (size_t)((n + 1) & ~1ull) : 0);
+        const size_t list_words = list2_at + (size_t)(n + 4) + (ordered ? (size_t)(2 * n) : 0);
         const size_t ckpt_bytes = seg2 ? (size_t)s2blocks * fdh::kS2Waves * fdh::kS2CkptPerWave * sizeof(uint2) : 0;
         const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);  // LZ-window kernel: persistent wavefronts
         const size_t lzck_bytes = (flags & 0x1000u) ? 0 : (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
@@ -834,13 +860,15 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             if (ordered) {
                 uint32_t* order = list + list2_at + (n + 4);
                 uint32_t* counters = list + (n + 4);
-                hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in_off, (uint32_t)n, order, counters);
+                hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, in_off, (uint32_t)n, order, counters,
+                                   canon->hdr, status, fdh::kPending, sa.list2);
                 e = hipGetLastError();
                 if (e != hipSuccess) {
                     (void)hipFreeAsync(list, stream);
                     return (int)e;
                 }
                 sa.order = order;
+                sa.order_counts = counters;
             }
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
             e = hipGetLastError();

@@ -148,7 +148,8 @@ struct SegArgs {
     const uint32_t* canon_lit2;  // ... and its decode table (CanonTables::lit2)
     uint32_t* list2; // nullable (interval kernel): the list of the kernel BEHIND the segment kernel -- streams without
                      // the ultra-fast prefix go there directly, the segment kernel would only look at them and pass them on
-    const uint32_t* order;  // nullable (interval kernel): the order in which the streams are handed out (long ones first)
+    const uint32_t* order;  // nullable (interval kernel): the order in which the streams are handed out (long ones first, [0 ..); short ones [n ..))
+    const uint32_t* order_counts;  // ... and how many of each
 };
 
 // Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).
