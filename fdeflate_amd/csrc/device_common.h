@@ -69,6 +69,23 @@ __device__ __forceinline__ uint32_t bytedot4(uint32_t x, uint32_t w, uint32_t ac
     return __builtin_amdgcn_udot4(x, w, acc, false);
 }
 
+
+// Inclusive prefix sum / maximum over the 64 lanes with DPP moves (row shifts inside the rows of 16 lanes, then the
+// two row broadcasts of gfx9): no LDS traffic, a dozen instructions.  All 64 lanes must be active.
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    auto op = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return MAX ? (a > b ? a : b) : a + b; };
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) { return wave_scan_incl<false>(v); }
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) { return wave_scan_incl<true>(v); }
+
 constexpr uint32_t kAdlerMod = 65521u;
 
 // RFC-1951 length / distance symbol tables (reference src/tables.rs:68-88, data).

@@ -210,13 +210,7 @@ __device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
             sz[i] = m ? 1u << (m - kLzLitBits) : 0u;
             tot += sz[i];
         }
-        uint32_t incl = tot;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t y = __shfl_up(incl, d, kWave);
-            if (lane >= d) incl += y;
-        }
-        uint32_t off = incl - tot;
+        uint32_t off = wave_scan_add(tot) - tot;
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             if (sz[i]) {
@@ -782,21 +776,11 @@ __device__ __forceinline__ bool lz_parse_dynamic(LzLds& L, INF& inf, const uint3
         if (bad || nr > total) return false;  // an impossible code / a repeat beyond the last length
         const bool on = (chain >> lane) & 1;
         // where a lane's lengths go: exclusive prefix sum of the repeat counts along the chain
-        uint32_t incl = on ? rep : 0u;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t y = __shfl_up(incl, d, kWave);
-            if (lane >= d) incl += y;
-        }
+        const uint32_t incl = wave_scan_add(on ? rep : 0u);
         const uint32_t n0 = nread + incl - (on ? rep : 0u);
         // what "repeat the previous length" repeats: the nearest chain token below that is a length itself
         // (17 / 18 write zeros, and a 16 behind them repeats that zero)
-        uint32_t key = (on && sym != 16) ? (((uint32_t)lane + 1) << 8) | (sym <= 15 ? sym : 0u) : 0u;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t y = __shfl_up(key, d, kWave);
-            if (lane >= d) key = max(key, y);
-        }
+        const uint32_t key = wave_scan_max((on && sym != 16) ? (((uint32_t)lane + 1) << 8) | (sym <= 15 ? sym : 0u) : 0u);
         const uint32_t value = sym <= 15 ? sym : (sym == 16 ? (key ? (key & 0xFF) : prevlen) : 0u);
         if (__any(on && sym == 16 && n0 == 0)) return false;  // nothing to repeat (src/decompress.rs:513-529)
         // short tokens: every lane writes its own (up to four lengths); long repeats: the wavefront, one by one
@@ -897,12 +881,10 @@ __device__ __forceinline__ void lz_flush(LzLds& L, LzOut& o, const bool final, c
         ri = lz_wrap(ri + kWave * 16);
     }
     {
-        uint64_t A = acc_a, Bv = acc_b;
-#pragma unroll
-        for (int x = 32; x > 0; x >>= 1) {
-            A += __shfl_xor(A, x, kWave);
-            Bv += __shfl_xor(Bv, x, kWave);
-        }
+        // (lane sums fit 32 bits: at most 64 lines of 16 bytes per lane and flush; the weighted sum in two halves)
+        const uint64_t A = __builtin_amdgcn_readlane(wave_scan_add((uint32_t)acc_a), 63);
+        const uint64_t Bv = (uint64_t)__builtin_amdgcn_readlane(wave_scan_add((uint32_t)(acc_b & 0xFFFFFu)), 63) +
+                            ((uint64_t)__builtin_amdgcn_readlane(wave_scan_add((uint32_t)(acc_b >> 20)), 63) << 20);
         const uint64_t Lf = q_hi - q_lo;  // bytes of this flush
         o.adler_b = (uint32_t)(((uint64_t)o.adler_b + Lf * o.adler_a + Bv) % kAdlerMod);
         o.adler_a = (uint32_t)((o.adler_a + A) % kAdlerMod);
@@ -1205,13 +1187,7 @@ __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBou
             item = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
         }
         const uint32_t cnt = item.y & 0xFFFF, nm = item.y >> 16;
-        uint64_t incl64 = (uint64_t)cnt | ((uint64_t)nm << 32);
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint64_t y = __shfl_up(incl64, d, kWave);
-            if (lane >= d) incl64 += y;
-        }
-        const uint32_t incl = (uint32_t)incl64, incl_m = (uint32_t)(incl64 >> 32);
+        const uint32_t incl = wave_scan_add(cnt), incl_m = wave_scan_add(nm);
         const int nuse = __popcll(__ballot(have && incl <= kLzImgCap && incl_m <= kLzIdxCap));
         if (nuse == 0) {  // the first item alone is too much for an image: again from there, with shorter phases
             bitpos = __builtin_amdgcn_readfirstlane(item.x) - mis8;
