@@ -84,7 +84,8 @@ struct __attribute__((aligned(16))) LzWork {
     uint32_t stage[kLzStageDw];    // the span's stream bytes (coalesced copy)
     uint16_t idx[kLzIdxCap + 2];   // where the image's matches start, in stream order (+ a spare entry for stores that are not wanted)
 };
-constexpr uint32_t kLzSub = 512;  // second-level entries of the literal/length table (codes beyond its index)
+constexpr uint32_t kLzSub = 384;   // second-level entries of the literal/length table (codes beyond its index)
+constexpr uint32_t kLzDsub = 128;  // ... and of the distance table
 // Decode tables of the current block in the walk's entry layout (below), with the canonical bookkeeping the
 // second level and the slow step read.
 struct __attribute__((aligned(16))) LzTables {
@@ -98,6 +99,7 @@ struct __attribute__((aligned(16))) LzTables {
 struct __attribute__((aligned(16))) LzLds {
     LzTables tables;
     uint32_t sub[kLzSub];          // second level of tables.lit (lz_build_sub)
+    uint32_t dsub[kLzDsub];        // second level of tables.dist
     union {
         // block headers are parsed by the wave-serial reader (inflate_stream.h) between spans: it only ever
         // touches WaveIo::in_ring (its first member): the tables are this kernel's own business
@@ -138,9 +140,10 @@ __device__ unsigned long long g_lzstat[32];
 //               3 code beyond the index with a second level: [4:0] its index bits (stream bits 10 ..), [27:8] its
 //               first entry in LzLds::sub (entries there are literal / length / end-of-block entries with the full code length)
 //   distance, index = low 9 bits:
-//     [4:0] code + extra bits, [8:5] code bits, [12:9] extra bits, [31:16] base; bit 13 special ([14]: code beyond the index)
+//     [4:0] code + extra bits, [8:5] code bits, [12:9] extra bits, [31:16] base; bit 13 special ([14]: code beyond the index,
+//     canonical walk; [15]: code beyond the index with a second level: [4:0] its index bits, [31:16] its first entry in LzLds::dsub)
 constexpr uint8_t kClclOrderHost[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // src/tables.rs:63-65
-constexpr uint32_t LZW_LEN = 1u << 31, LZW_SPECIAL = 1u << 30, LZD_SPECIAL = 1u << 13, LZD_LONG = 1u << 14;
+constexpr uint32_t LZW_LEN = 1u << 31, LZW_SPECIAL = 1u << 30, LZD_SPECIAL = 1u << 13, LZD_LONG = 1u << 14, LZD_TWO = 1u << 15;
 constexpr uint32_t LZW_TWO = LZW_SPECIAL | (3u << 28);  // (e & LZW_TWO) == LZW_TWO: second-level look-up
 
 __device__ __forceinline__ uint32_t lz_conv_lit(uint32_t e) {
@@ -167,19 +170,26 @@ __device__ __forceinline__ uint32_t lz_conv_dist(uint32_t de) {
 // this kernel's entry layout): every 10-bit prefix that longer codes share gets 2^(longest - 10) entries
 // of LzLds::sub.  Prefixes that do not fit keep the canonical-walk marker.
 // Call after lz_convert_tables; CodeBook / sorted symbols as build_table left them.
-__device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
+template <bool DIST>
+__device__ __forceinline__ void lz_build_sub_t(LzLds& L, int lane) {
     LzTables& T = L.tables;
-    const CodeBook& cb = T.lit_cb;
-    constexpr int NL = kLzLitLong;  // lengths kLzLitBits + 1 .. 15
+    constexpr int BITS = DIST ? kLzDistBits : kLzLitBits;
+    constexpr int NL = 15 - BITS;  // lengths BITS + 1 .. 15
+    constexpr uint32_t MASK = (1u << BITS) - 1, CAP = DIST ? kLzDsub : kLzSub;
+    const CodeBook& cb = DIST ? T.dist_cb : T.lit_cb;
+    const uint16_t* const sorted = DIST ? T.dist_sorted : T.lit_sorted;
+    uint32_t* const prim = DIST ? T.dist : T.lit;
+    uint32_t* const sub = DIST ? L.dsub : L.sub;
     uint32_t nsyms = 0, offs[NL], first[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        offs[i] = uni(cb.offs[kLzLitBits + 1 + i]);
-        first[i] = uni(cb.first[kLzLitBits + 1 + i]);
+        offs[i] = uni(cb.offs[BITS + 1 + i]);
+        first[i] = uni(cb.first[BITS + 1 + i]);
     }
     nsyms = offs[NL - 1] + uni(cb.hist[15]);
     if (nsyms == offs[0]) return;  // no code beyond the index
-    constexpr uint32_t kWalk = LZW_SPECIAL | (1u << 28);  // what the table fill left in the shared prefixes
+    // what the table fill left in the shared prefixes: "code beyond the index: canonical walk"
+    constexpr uint32_t kWalk = DIST ? (LZD_SPECIAL | LZD_LONG) : (LZW_SPECIAL | (1u << 28));
     auto code_of = [&](uint32_t j, uint32_t& l, uint32_t& rev) __attribute__((always_inline)) {
         uint32_t li = 0;
 #pragma unroll
@@ -190,32 +200,33 @@ __device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
             o = vsel(li == (uint32_t)i, offs[i], o);
             f = vsel(li == (uint32_t)i, first[i], f);
         }
-        l = kLzLitBits + 1 + li;
+        l = BITS + 1 + li;
         rev = __brev(f + (j - o)) >> (32 - l);
     };
     // the longest code of every prefix, kept in the prefix's own entry: marker | length
     for (uint32_t j = offs[0] + (uint32_t)lane; j < nsyms; j += kWave) {
         uint32_t l, rev;
         code_of(j, l, rev);
-        atomicMax(&T.lit[rev & kLzLitMask], kWalk | l);
+        atomicMax(&prim[rev & MASK], kWalk | l);
     }
     wave_sync();
     {   // allocation: lane i owns the prefixes PER i .. PER i + PER - 1
-        constexpr int PER = (1 << kLzLitBits) / kWave;
+        constexpr int PER = (1 << BITS) / kWave;
         uint32_t sz[PER], tot = 0;
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const uint32_t e = T.lit[PER * lane + i];
+            const uint32_t e = prim[PER * lane + i];
             const uint32_t m = (e & 0xFFFFFFE0u) == kWalk ? (e & 31) : 0u;
-            sz[i] = m ? 1u << (m - kLzLitBits) : 0u;
+            sz[i] = m ? 1u << (m - BITS) : 0u;
             tot += sz[i];
         }
         uint32_t off = wave_scan_add(tot) - tot;
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             if (sz[i]) {
-                const uint32_t m = T.lit[PER * lane + i] & 31;
-                T.lit[PER * lane + i] = off + sz[i] <= kLzSub ? (LZW_TWO | (off << 8) | (m - kLzLitBits)) : kWalk;
+                const uint32_t m = prim[PER * lane + i] & 31;
+                const uint32_t two = DIST ? (LZD_SPECIAL | LZD_TWO | (off << 16) | (m - BITS)) : (LZW_TWO | (off << 8) | (m - BITS));
+                prim[PER * lane + i] = off + sz[i] <= CAP ? two : kWalk;
                 off += sz[i];
             }
         }
@@ -224,15 +235,27 @@ __device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
     for (uint32_t j = offs[0] + (uint32_t)lane; j < nsyms; j += kWave) {
         uint32_t l, rev;
         code_of(j, l, rev);
-        const uint32_t t = T.lit[rev & kLzLitMask];
-        if ((t & LZW_TWO) != LZW_TWO) continue;  // did not fit: the canonical walk stays
-        const uint32_t longest = kLzLitBits + (t & 31), off = (t >> 8) & 0xFFFFF;
-        const uint32_t e = lz_conv_lit(LitlenTraitsT<kLzLitBits>::entry(T.lit_sorted[j], l));
-        const uint32_t step = 1u << (l - kLzLitBits), n = 1u << (longest - l);
-        uint32_t at = off + (rev >> kLzLitBits);
-        for (uint32_t i = 0; i < n; i++, at += step) L.sub[at] = e;
+        const uint32_t t = prim[rev & MASK];
+        uint32_t longest, off;
+        if (DIST) {
+            if ((t & (LZD_SPECIAL | LZD_TWO)) != (LZD_SPECIAL | LZD_TWO)) continue;  // did not fit: the canonical walk stays
+            longest = BITS + (t & 31);
+            off = t >> 16;
+        } else {
+            if ((t & LZW_TWO) != LZW_TWO) continue;
+            longest = BITS + (t & 31);
+            off = (t >> 8) & 0xFFFFF;
+        }
+        const uint32_t e = DIST ? lz_conv_dist(DistTraits::entry(sorted[j], l)) : lz_conv_lit(LitlenTraitsT<kLzLitBits>::entry(sorted[j], l));
+        const uint32_t step = 1u << (l - BITS), n = 1u << (longest - l);
+        uint32_t at = off + (rev >> BITS);
+        for (uint32_t i = 0; i < n; i++, at += step) sub[at] = e;
     }
     wave_sync();
+}
+__device__ __forceinline__ void lz_build_sub(LzLds& L, int lane) {
+    lz_build_sub_t<false>(L, lane);
+    lz_build_sub_t<true>(L, lane);
 }
 
 struct LzTok {
@@ -257,7 +280,7 @@ __device__ __forceinline__ LzBounds lz_load_bounds(const LzTables& T) {
 
 // The token in front of (hi:lo), every case: codes beyond the primary tables are resolved against the
 // canonical bounds (long_walk of inflate_tables.h with the bounds in registers).
-__device__ __forceinline__ LzTok lz_token_slow(const LzTables& T, const uint32_t* sub, const LzBounds& bd, uint32_t lo, uint32_t hi) {
+__device__ __forceinline__ LzTok lz_token_slow(const LzTables& T, const uint32_t* sub, const uint32_t* dsub, const LzBounds& bd, uint32_t lo, uint32_t hi) {
     LzTok t;
     t.kind = 3;
     t.bits = t.n = t.v = 0;
@@ -291,6 +314,7 @@ __device__ __forceinline__ LzTok lz_token_slow(const LzTables& T, const uint32_t
     const uint32_t length = ((e >> 16) & 0x1FF) + __builtin_amdgcn_ubfe(lo, nb, ex);
     const uint32_t dv = __builtin_amdgcn_alignbit(hi, lo, tb);
     uint32_t de = T.dist[dv & kLzDistMask];
+    if ((de & (LZD_SPECIAL | LZD_TWO)) == (LZD_SPECIAL | LZD_TWO)) de = dsub[(de >> 16) + __builtin_amdgcn_ubfe(dv, kLzDistBits, de & 31)];
     if (de & LZD_SPECIAL) {
         if (!(de & LZD_LONG)) return t;
         const uint32_t r16 = __brev(dv) >> 16;
@@ -366,7 +390,12 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
             const bool is_len = (int32_t)e < 0;
             const uint32_t length = ((e >> 16) & 0x1FF) + __builtin_amdgcn_ubfe(lo, (e >> 8) & 15, (e >> 5) & 7);
             const uint32_t dv = __builtin_amdgcn_alignbit(hi, lo, tb);
-            const uint32_t de = T.dist[dv & kLzDistMask];
+            uint32_t de = T.dist[dv & kLzDistMask];
+            {   // a distance code beyond the index: its second-level entry (every lane looks one up: no branch)
+                const bool two = (de & (LZD_SPECIAL | LZD_TWO)) == (LZD_SPECIAL | LZD_TWO);
+                const uint32_t d2 = L.dsub[two ? (de >> 16) + __builtin_amdgcn_ubfe(dv, kLzDistBits, de & 31) : 0u];
+                de = two ? d2 : de;
+            }
             special = (e & LZW_SPECIAL) != 0 || (is_len && (de & LZD_SPECIAL) != 0);  // (of the last step: what the slow step looks at)
             const uint32_t bits = tb + (is_len ? (de & 31) : 0u);
             const uint32_t inc = is_len ? length : ((e >> 5) & 3);
@@ -399,7 +428,7 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
                 const uint32_t rel = act ? pos - bit0 : 0u, di = rel >> 5, sh = rel & 31;
                 const uint32_t r0 = slot[di], r1 = slot[di + 1], r2 = slot[di + 2];
                 const uint32_t lo = __builtin_amdgcn_alignbit(r1, r0, sh), hi = __builtin_amdgcn_alignbit(r2, r1, sh);
-                const LzTok tk = lz_token_slow(T, L.sub, bd, lo, hi);
+                const LzTok tk = lz_token_slow(T, L.sub, L.dsub, bd, lo, hi);
                 if (slows) *slows += 1;
                 if (act) {
                     if (tk.kind >= 2) {
