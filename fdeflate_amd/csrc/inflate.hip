@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
 // counters: [0] long, [1] short, zeroed.
 __global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, const uint64_t* in_off, uint32_t n, uint32_t* order,
                                                            uint32_t* counters, const uint32_t* canon_hdr, uint32_t* status,
-                                                           uint32_t pending, uint32_t* list2) {
+                                                           uint32_t pending, uint32_t* list2, uint32_t second) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t thr = (in_off[n] - in_off[0]) / n / 2;
@@ -521,9 +521,11 @@ __global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, co
         }
         canon = w0 == canon_hdr[0] && w1 == canon_hdr[1];
     }
-    const bool other = valid && !canon;
-    const bool big = canon && len >= thr;
-    const bool small = canon && !big;
+    // (the other streams' list is walked from the front by persistent wavefronts too: the long ones are listed by
+    //  the first launch of this kernel, the short ones behind them by a second launch, `second`)
+    const bool other = valid && !canon && ((len >= thr) != (second != 0));
+    const bool big = canon && len >= thr && !second;
+    const bool small = canon && len < thr && !second;
     const uint64_t mb = __ballot(big), ms = __ballot(small), mo = __ballot(other);
     uint32_t base_b = 0, base_s = 0, base_o = 0;
     if (lane == 0) {
@@ -860,8 +862,9 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             if (ordered) {
                 uint32_t* order = list + list2_at + (n + 4);
                 uint32_t* counters = list + (n + 4);
-                hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, in_off, (uint32_t)n, order, counters,
-                                   canon->hdr, status, fdh::kPending, sa.list2);
+                for (uint32_t second = 0; second < 2; second++)
+                    hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, in_off, (uint32_t)n, order,
+                                       counters, canon->hdr, status, fdh::kPending, sa.list2, second);
                 e = hipGetLastError();
                 if (e != hipSuccess) {
                     (void)hipFreeAsync(list, stream);

@@ -1206,15 +1206,16 @@ __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBou
     const uint32_t T = (uint32_t)nvalid * P;
     const uint32_t recipP = 65536u / P + 1;  // t / P for t < 1024
     uint32_t t0 = 0;
+    auto load_item = [&](uint32_t t) __attribute__((always_inline)) -> unsigned long long {
+        // (always issued: the next image's items are requested while this image is decoded)
+        return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(in.ck + min(t, T - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    unsigned long long raw_next = load_item((uint32_t)lane);
     while (t0 < T) {
         const uint32_t t = t0 + (uint32_t)lane;
         const bool have = t < T;
-        uint2 item = make_uint2(0, 0);
-        if (have) {
-            const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(in.ck + t), __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT);
-            item = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
-        }
+        const unsigned long long raw = raw_next;
+        const uint2 item = have ? make_uint2((uint32_t)raw, (uint32_t)(raw >> 32)) : make_uint2(0, 0);
         const uint32_t cnt = item.y & 0xFFFF, nm = item.y >> 16;
         const uint32_t incl = wave_scan_add(cnt), incl_m = wave_scan_add(nm);
         const int nuse = __popcll(__ballot(have && incl <= kLzImgCap && incl_m <= kLzIdxCap));
@@ -1224,6 +1225,7 @@ __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBou
         }
         const uint32_t N = __builtin_amdgcn_readlane(incl, nuse - 1), nmatch = __builtin_amdgcn_readlane(incl_m, nuse - 1);
         if (N > in.cap - o.O) return LZ_BAIL;  // OutputTooLarge is the exact kernels' business
+        raw_next = load_item(t + (uint32_t)nuse);
         LZT(o, 4);
         // ---- pass 2 ----
         const bool mine = lane < nuse && cnt != 0;
