@@ -47,7 +47,7 @@ constexpr uint32_t kLzLitMask = (1u << kLzLitBits) - 1, kLzDistMask = (1u << kLz
 constexpr int kLzLitLong = 15 - kLzLitBits, kLzDistLong = 15 - kLzDistBits;  // code lengths beyond the indices
 static_assert(kLzLitBits >= 9 && kLzLitBits <= 12 && kLzDistBits >= 7 && kLzDistBits <= 10, "table index bits");
 #ifndef FDH_LZ_RING
-#define FDH_LZ_RING 3072
+#define FDH_LZ_RING 3584
 #endif
 #ifndef FDH_LZ_WAVES_PER_CU
 #define FDH_LZ_WAVES_PER_CU 11
@@ -56,7 +56,7 @@ static_assert(kLzLitBits >= 9 && kLzLitBits <= 12 && kLzDistBits >= 7 && kLzDist
 #define FDH_LZ_RANGE 192
 #endif
 #ifndef FDH_LZ_IMG
-#define FDH_LZ_IMG 2560
+#define FDH_LZ_IMG 3328
 #endif
 #ifndef FDH_LZ_WARM
 #define FDH_LZ_WARM 192
@@ -78,14 +78,20 @@ constexpr uint32_t kLzSlotDw = ((31 + kLzRange + 96 + 31) / 32) | 1u;
 constexpr uint32_t kLzStageDw = 64 * kLzSlotDw;
 static_assert(kLzStageDw >= 256, "the far buffer and the header parser borrow the first KiB of the stage");
 constexpr uint32_t kLzIdxCap = kLzImgCap / 4;  // matches of one span (a match is at least three bytes; the bench's zlib-6 streams: one per 5.2)
-static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 512, "ring = image + history");
+static_assert(kLzRing % 64 == 0 && kLzRing >= kLzImgCap + 256, "ring = image + history");
 
 struct __attribute__((aligned(16))) LzWork {
     uint32_t stage[kLzStageDw];    // the span's stream bytes (coalesced copy)
     uint16_t idx[kLzIdxCap + 2];   // where the image's matches start, in stream order (+ a spare entry for stores that are not wanted)
 };
-constexpr uint32_t kLzSub = 384;   // second-level entries of the literal/length table (codes beyond its index)
-constexpr uint32_t kLzDsub = 128;  // ... and of the distance table
+#ifndef FDH_LZ_SUB
+#define FDH_LZ_SUB 256
+#endif
+#ifndef FDH_LZ_DSUB
+#define FDH_LZ_DSUB 64
+#endif
+constexpr uint32_t kLzSub = FDH_LZ_SUB;   // second-level entries of the literal/length table (codes beyond its index)
+constexpr uint32_t kLzDsub = FDH_LZ_DSUB;  // ... and of the distance table
 // Decode tables of the current block in the walk's entry layout (below), with the canonical bookkeeping the
 // second level and the slow step read.
 struct __attribute__((aligned(16))) LzTables {
