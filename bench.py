@@ -670,7 +670,8 @@ def main():
                                              "(fdh_png_filter_deflate_ultrafast_batch) of the %d images" % n,
                                  "metric": "input GB/s", "value": round(n * rows_png * rb_png / (w5 / psteps) / 1e9, 3),
                                  "ms_per_step": round(w5 * 1e3 / psteps, 4), "steps": psteps,
-                                 "roofline": roofline(falg, sum(k5) / len(k5), "deflate_ultrafast_kernel_t<true>", None)})
+                                 "roofline": roofline(falg, sum(k5) / len(k5), "deflate_ultrafast_kernel_t<true>",
+                                                      profiled_traffic("filterenc") if full else None)})
                     del fenc, types
                 except Exception as e:
                     also.append({"workload": "SURVEY 8f: PNG filter + ultra-fast encode", "error": repr(e)})

@@ -61,15 +61,23 @@ if enc:
     step["encode"] = {"hbm_bytes_per_step": enc, "kernels": [k for k in traffic if "deflate" in k],
                       "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes"}
 # the "also" lines of bench.py (profiled one by one: tools/profile.sh <tag> --also-select <name> ...)
-png = sum(t["hbm_bytes_per_launch"] for k, t in traffic.items() if "png_" in k)
+# (only the kernels of the timed step: png_wave_kernel is a one-off property-check launch of bench.py, not part of it)
+png = sum(t["hbm_bytes_per_launch"] for k, t in traffic.items() if "png_pipe" in k)
+fenc = sum(t["hbm_bytes_per_launch"] for k, t in traffic.items() if "deflate_ultrafast_kernel_t<true>" in k or "deflate_ultrafast_kernel_t<(bool)1>" in k)
 gen = sum(t["hbm_bytes_per_launch"] for k, t in traffic.items() if "deflate_parse" in k or "deflate_write" in k)
 also_key = os.environ.get("FDH_PROFILE_KEY", "")
 if also_key == "png" and png:
-    step = {"png": {"hbm_bytes_per_step": png + dec, "kernels": [k for k in traffic if "png_" in k or "inflate" in k],
+    step = {"png": {"hbm_bytes_per_step": png + dec, "kernels": [k for k in traffic if "png_pipe" in k or "inflate" in k],
                     "note": "decode kernels + reconstruction kernel of one fdh_inflate_png_batch call"}}
+    if fenc:
+        step["filterenc"] = {"hbm_bytes_per_step": fenc, "kernels": [k for k in traffic if "deflate_ultrafast_kernel_t" in k and "true" in k or "(bool)1" in k],
+                             "note": "the fused filter + ultra-fast encode kernel of one fdh_png_filter_deflate_ultrafast_batch call"}
 elif also_key in ("level1", "rle") and gen:
     step = {also_key: {"hbm_bytes_per_step": gen, "kernels": [k for k in traffic if "deflate_parse" in k or "deflate_write" in k],
                        "note": "parser + block writer of one fdh_deflate_general_batch call"}}
+elif also_key == "mix" and dec:
+    step = {"mix": {"hbm_bytes_per_step": dec, "kernels": step["decode"]["kernels"],
+                    "note": "all decode kernels of one fdh_inflate_batch call on the mixed batch"}}
 elif also_key == "zlib6" and dec:
     step = {"zlib6": {"hbm_bytes_per_step": dec, "kernels": step["decode"]["kernels"],
                       "note": "all decode kernels of one fdh_inflate_batch call on zlib level-6 streams"}}
