@@ -364,14 +364,17 @@ def cpu_baseline(args, comp, c_off, native_so):
 # ------------------------------------------------------------------------------------------
 
 def kernel_source_sha():
-    """Hash of the kernel sources: the PMC traffic figure of profiles/ is only quoted when it was
-    measured on exactly this code."""
+    """Hash of the kernel sources (comment-only and blank lines aside: they do not change the machine
+    code): the PMC traffic figure of profiles/ is only quoted when it was measured on exactly this code."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fdeflate_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".h", ".hip", ".cpp", ".inc")):
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            for line in open(os.path.join(d, name), "rb").read().split(b"\n"):
+                t = line.strip()
+                if t and not t.startswith(b"//"):
+                    h.update(t + b"\n")
     return h.hexdigest()[:16]
 
 

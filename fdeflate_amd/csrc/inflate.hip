@@ -126,11 +126,12 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
     if (a.only_pending) {
         uint32_t st = a.status[sid];
         if (st != kPending && st != kPendingSerial) return;
-        if (st == kPendingSerial) tiles = false;
     }
     const StreamArgs s = stream_args(a, sid);
     Inflater inf(lds.tables, lds.io, &lds.hs, lane);
     StreamResult r;
+    ResumePoint rp;
+    rp.valid = 0;
     if (tiles) {
         // the span decoder lists matches in global scratch: take one of the pool's slots
         uint32_t slot = kSpanSlots;
@@ -142,6 +143,12 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
             slot = uni(slot);
             inf.span_list = a.span_pool + kSpanSlots + (size_t)slot * (2 * kSpanMaxMatches);
         }
+        // The tiles of this kernel follow the reference's own chain of table steps (12-bit tables, its pairing
+        // of literals), so the state in front of a tile is a state the reference passes through: check points
+        // are taken there, and a result the tiles may have classified differently is re-derived by the exact
+        // serial decoder from the last of them -- the tail of the stream, not the stream (round 3: a damaged
+        // stream cost a serial pass over all of it).
+        inf.keep_ck = !(a.flags & 0x4000u);
         inf.init(s);
         r = inf.run<true, false>();
         if (slot < kSpanSlots) {
@@ -149,11 +156,21 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
             if (lane == 0) atomicExch(&a.span_pool[slot], 0u);
         }
         inf.span_list = nullptr;
-        if (needs_serial_recheck(r, a.flags)) tiles = false;
+        inf.keep_ck = false;
+        if (needs_serial_recheck(r, a.flags)) {
+            tiles = false;
+            rp = inf.ck;
+        }
     }
     if (!tiles) {
         inf.init(s);
-        r = inf.run<false, false>();
+        bool whole = true;
+        if (rp.valid) {
+            r = inf.run_from<false>(rp);
+            whole = r.status == RC_REDO;  // the stream ended before the tail fell in step with the reference's table steps
+            if (whole) inf.init(s);
+        }
+        if (whole) r = inf.run<false, false>();
     }
     if (lane == 0) {
         a.status[sid] = r.status;

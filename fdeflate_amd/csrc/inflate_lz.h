@@ -5,27 +5,32 @@
 // src/decompress.rs:611-1018 (match copy :782-829), with the tables of src/huffman.rs:18-184 as
 // inflate_tables.h builds them.  tests/lz_model.py is an executable CPU model of the algorithm.
 //
-// A block's data is decoded in SPANS of 64 x R stream bits, one bit range per lane:
+// A block's data is decoded in SUPER-SPANS of 64 x P x Q stream bits (Q = kLzRange, P <= kLzMaxPhases): lane l owns
+// the P x Q bits from l P Q on and walks them in P phases of Q bits (lz_superspan, at the end of this file):
 //
-//   pass 1   a lane walks a guessed chain from up to kLzWarm bits in front of its range (impossible
-//            tokens slide on by one bit; Huffman codes self-synchronise: 86 % of the guesses of the bench's
-//            zlib-6 streams have merged with the real chain after 256 bits) and counts the output bytes of
-//            the table steps that START inside its range.
-//   check    a lane's first step at or behind its range start must be where its left neighbour's
-//            chain left the neighbour's range; by induction from lane 0 (whose start is real) every
-//            counted chain is then the real one.  Lanes that fail walk again from the neighbour's end.
-//   offsets  a wavefront prefix sum; the span takes as many lanes as fit the image (and ends with the
-//            lane that meets the end-of-block code: the lanes behind it decoded with stale tables).
-//   pass 2   decodes again: literals go to the IMAGE -- the span's output, which lives in a ring in LDS
-//            together with the history in front of it -- a match leaves a 3-byte descriptor
-//            (length - 3, distance - 1) in the first three bytes of its place and an entry in the span's match list.
-//   resolve  by match, 64 at a time in stream order (lane = match; pass 2 lists where the matches start):
-//            a match whose source bytes end in front of the batch's first match depends on nothing that is
-//            still missing -- nine in ten on the bench data -- and all of those are copied at once, a lane
-//            each; the others follow in order against a frontier.  Long or self-overlapping matches are
-//            copied by the whole wavefront.  Sources older than the ring come from the output slot in global
-//            memory (L2), one unaligned 16-B load per match, requested a batch ahead.
+//   pass 1   a lane walks a guessed chain from up to kLzWarm bits in front of its range (impossible tokens slide
+//            on by one bit; Huffman codes self-synchronise: 86 % of the guesses of the bench's zlib-6 streams have
+//            merged with the real chain after 256 bits), then its phases; per phase it leaves an ITEM in global
+//            scratch: where the phase's first step starts, the output bytes and the matches of the steps that
+//            START in the phase.
+//   check    a lane's first step must be where its left neighbour's chain left the neighbour's range; by
+//            induction from lane 0 (whose start is real) every chain is then the real one.  Lanes that fail walk
+//            again from the neighbour's end until they meet their old chain at a phase boundary.
+//   images   the items in lane-major order are the stream in order.  64 items at a time (as many as fit an IMAGE
+//            of kLzImgCap output bytes / kLzIdxCap matches): output offsets by a wavefront prefix sum, then
+//   pass 2   a lane decodes its item again: literals go to the image -- the next piece of the output ring in LDS,
+//            which also holds the history in front of it -- a match leaves a 3-byte descriptor (length - 3,
+//            distance - 1) in the first three bytes of its place and an entry in the image's match list.
+//   resolve  by match, 64 at a time in stream order (lane = match): a match whose source bytes end in front of the
+//            batch's first match depends on nothing that is still missing -- nine in ten on the bench data -- and
+//            all of those are copied at once, a lane each; the others follow in order against a frontier.  Long or
+//            self-overlapping matches are copied by the whole wavefront.  Sources older than the ring come from the
+//            output slot in global memory (L2): four unaligned dword loads per match, requested a batch ahead.
 //   flush    whole 16-B lines of the image to the slot, the Adler-32 folded in (as flush_ring).
+//
+// Tables are the kernel's own (lz_build_tables / lz_parse_dynamic): a 9-bit literal/length table whose entries
+// carry up to two literals, or a length with its extra bits, and an 8-bit distance table, each with a second level
+// (kLzSub / kLzDsub entries) for the longer codes; what fits neither takes the canonical walk of lz_token_slow.
 //
 // The kernel only ever reports Ok: anything else (stored blocks, errors, truncation, a slot that is
 // too small, a wrong checksum) leaves the stream PENDING for the exact kernels behind it.

@@ -82,7 +82,19 @@ struct StreamResult {
     bool ambiguous;  // ended "stuck" close to the end of the input (see inflate.hip)
 };
 
-enum : uint32_t { RC_OK = 0, RC_EOB = 0x100, RC_STUCK = 0x101 };  // anything else: a StreamStatus
+// A place a decoder can start from instead of the stream's first byte: a symbol boundary inside a Huffman block
+// (`bit` > `hdr_bit`) or the header of a block (`bit` == `hdr_bit`).  Everything in front of it is decoded: the
+// bytes [0, opos) are in the output slot in global memory, `adler` is their Adler-32.  The block's tables are
+// rebuilt from its header, which is why that is part of the point.
+struct ResumePoint {
+    uint64_t hdr_bit;  // stream bit of the block header
+    uint64_t bit;      // stream bit to go on from
+    uint32_t opos;
+    uint32_t adler;
+    uint32_t valid;
+};
+
+enum : uint32_t { RC_OK = 0, RC_EOB = 0x100, RC_STUCK = 0x101, RC_REDO = 0x102 };  // anything else: a StreamStatus
 
 #ifdef FDH_DEBUG_TILES
 __device__ uint32_t g_dbg[1 << 16];
@@ -186,12 +198,16 @@ struct InflaterT {
     uint32_t serial_credit;  // tokens to decode serially before the next tile attempt
     uint32_t* span_list;     // scratch of this workgroup: kSpanMaxMatches x {at, length | dist << 16}; null: no spans
     uint32_t span_credit;    // tiles to run before the next span attempt (after a span that did not pay)
+    // ---- check points (inflate_general_kernel: the exact serial decoder then only re-derives the tail) ----
+    bool keep_ck;            // take a check point at every block header and in front of every tile
+    uint64_t hdr_bit;        // where the current block's header starts
+    ResumePoint ck;          // the last check point
 #ifdef FDH_DEBUG_TILES
     unsigned long long gacc[24] = {};
 #endif
 
     __device__ __forceinline__ InflaterT(TableSetT<LB>& t, WaveIo& w, HeaderScratch* h, int ln)
-        : T(t), io(w), hs(h), lane(ln), span_list(nullptr) {}
+        : T(t), io(w), hs(h), lane(ln), span_list(nullptr), keep_ck(false) {}
 
     // ------------------------------------------------------------------ input window
     __device__ __forceinline__ void load_chunk(uint32_t c) {
@@ -393,7 +409,37 @@ struct InflaterT {
         flags = a.flags;
         serial_credit = 0;
         span_credit = 0;
+        hdr_bit = 0;
+        ck.valid = 0;
         seek(0);
+    }
+
+    // ------------------------------------------------------------------ check points
+    // Everything decoded so far goes to the slot (partial line included: the next flush goes on from an odd
+    // position, as the first one of a misaligned slot does) and the place is noted.  Only ever called at a
+    // boundary between two table steps of the reference's chain: at a block header, in front of a tile.
+    __device__ __forceinline__ void take_ck() {
+        flush(true);
+        ck.hdr_bit = hdr_bit;
+        ck.bit = consumed_bits();
+        ck.opos = opos;
+        ck.adler = (adler_b << 16) | adler_a;
+        ck.valid = 1;
+    }
+    __device__ __forceinline__ void seek_to(uint64_t bit) {
+        seek(bit);
+        left = (win_bytes - mis) * 8 - bit;
+    }
+    // The last kOutRing - 16 bytes of the output (or all of it) from the slot into the ring: the history of a
+    // decoder that starts at a resume point.
+    __device__ __forceinline__ void reload_out_ring() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        const uint32_t lo_p = opos > (uint32_t)(kOutRing - 16) ? opos - (kOutRing - 16) : 0;
+        const uint8_t* const g = out_al + gmis;
+        for (uint32_t p = lo_p + (uint32_t)lane; p < opos; p += kWave)
+            io.out_ring[(p + gmis) & kOutMask] = __hip_atomic_load(g + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wave_sync();
     }
 
     // ------------------------------------------------------------------ zlib header
@@ -598,6 +644,41 @@ struct InflaterT {
         copy_match(n, dist);
         if (n < length) return RC_STUCK;  // remainder queued, output full
         return RC_OK;
+    }
+
+    // The exact serial decoder taking over at a SYMBOL boundary in the middle of a block (a check point in front
+    // of a tile, a resume point left by another kernel).  The reference walks the block table step by table step
+    // (src/decompress.rs:836-1015), and a step is one symbol -- or two literals whose codes fit the table index
+    // together (src/huffman.rs:110-130); where it stops when the input runs out depends on which symbols were
+    // paired: `if bit_buffer.nbits < litlen_code_bits { break }` (:852) holds back BOTH literals of a pair.
+    // So a symbol boundary is not enough to take over: it has to be the start of a step.  What is known:
+    //   * a symbol that is no literal of the table (a length, end-of-block, a code beyond the index) is a
+    //     step of its own: it starts one, and the next step starts behind it;
+    //   * a literal whose table entry is a single (it cannot pair with what follows) ends a step whichever way
+    //     it was reached: the next symbol starts a step;
+    //   * behind the first literal of a pair entry the position stays in doubt (second half of that pair, or
+    //     a step of its own if the step started one symbol earlier).
+    // This walks single symbols until the position is the start of a step for certain.  RC_OK: it is (go on
+    // with serial_token); RC_EOB: the block ended; RC_REDO: the stream ended, the slot filled up or an error
+    // turned up while the position was in doubt -- the caller decodes from the first byte, as rounds 1-3 did
+    // for every such stream; anything else: a result met at the start of a step, exact.
+    __device__ __forceinline__ uint32_t resync_to_step_start() {
+        for (;;) {
+            if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack - 264)) flush(false);
+            refill();
+            if (opos == cap) return RC_REDO;
+            const uint32_t e = uni(T.lit[(uint32_t)bb & (kLSize - 1)]);
+            const uint32_t nb = e & 15, kind = (e >> 4) & 15;
+            if (kind == K_LIT2) {  // first literal of a pair entry: the position behind it stays in doubt
+                if (left < nb) return RC_REDO;
+                put_byte((e >> 8) & 0xFF);
+                consume(e >> 24);
+                continue;
+            }
+            const uint32_t rc = serial_token();
+            if (kind == K_LIT1) return rc == RC_OK ? (uint32_t)RC_OK : (uint32_t)RC_REDO;
+            return rc;  // no literal of the table: this was the start of a step
+        }
     }
 
     // ------------------------------------------------------------------ tile decoder
@@ -1553,6 +1634,7 @@ struct InflaterT {
             if (TILES && serial_credit == 0 && opos < cap) {
                 uint32_t progress;
                 if (span_credit && span_credit != ~0u) span_credit--;
+                if (keep_ck) take_ck();
 #ifdef FDH_DEBUG_TILES
                 const long long t0 = clock64();
 #endif
@@ -1633,6 +1715,8 @@ struct InflaterT {
 #ifdef FDH_DEBUG_TILES
                 const long long th = clock64();
 #endif
+                hdr_bit = consumed_bits();
+                if (keep_ck) take_ck();
                 rc = parse_block_header();
 #ifdef FDH_DEBUG_TILES
                 GSTAT(8, clock64() - th);
@@ -1642,6 +1726,49 @@ struct InflaterT {
             } else {
                 rc = decode_block_data<TILES>();
             }
+            if (rc != RC_EOB) break;  // stuck or error
+            if (last_block) {
+                rc = read_trailer(stored);
+                break;
+            }
+            rc = RC_OK;
+        }
+        return finish(rc, stored);
+    }
+
+    // The rest of the stream from a resume point (init() has run): the zlib header is looked at all the same,
+    // the block header at rp.hdr_bit is parsed again for its tables.
+    template <bool TILES>
+    __device__ __forceinline__ StreamResult run_from(const ResumePoint rp) {
+        uint32_t rc = parse_zlib_header(), stored = 0;
+        if (rc == RC_OK) {
+            opos = flushed = rp.opos;
+            adler_a = rp.adler & 0xFFFF;
+            adler_b = rp.adler >> 16;
+            reload_out_ring();
+            seek_to(rp.hdr_bit);
+        }
+        bool first = true;
+        while (rc == RC_OK) {
+            hdr_bit = consumed_bits();
+            if (keep_ck && !first) take_ck();
+            rc = parse_block_header();
+            if (rc == RC_OK) {
+                if (first && rp.bit != rp.hdr_bit) {
+                    seek_to(rp.bit);
+                    rc = resync_to_step_start();
+                    if (rc == RC_REDO) {
+                        StreamResult r;
+                        r.status = RC_REDO;
+                        r.out_len = 0;
+                        r.adler = 0;
+                        r.ambiguous = true;
+                        return r;
+                    }
+                }
+                if (rc == RC_OK) rc = decode_block_data<TILES>();
+            }
+            first = false;
             if (rc != RC_EOB) break;  // stuck or error
             if (last_block) {
                 rc = read_trailer(stored);

@@ -74,6 +74,7 @@ enum {
 #define FDH_FLAG_INTERVALS_ONLY 0x800u /* debug: run only the interval kernel (what it leaves stays PENDING) */
 #define FDH_FLAG_NO_LZ          0x1000u /* tests/A-B: skip the LZ-window kernel (general streams go to the tile decoders) */
 #define FDH_FLAG_LZ_ONLY        0x2000u /* debug: nothing behind the LZ-window kernel runs (what it leaves stays PENDING) */
+#define FDH_FLAG_NO_CHECKPOINTS 0x4000u /* tests/A-B: the exact serial decoder re-derives a doubtful result from the stream's first byte, not from the last check point */
 #define FDH_FLAG_SPANS          0x100u /* experimental: segment-parallel "span" decoder inside the 12-bit general kernel */
 
 /*

@@ -451,6 +451,68 @@ def test_truncation_sweep(harness):
         harness.assert_inflate_parity(names, blobs, [cap] * len(blobs), flags=16)
 
 
+def _damaged_long_cases():
+    """Long streams cut short, bit-flipped and with damaged trailers: the cases whose classification the exact
+    serial decoder owns.  Several tiles / blocks lie in front of the damage, so the decoder re-derives the
+    result from a check point in the middle of the stream."""
+    import random
+    from fdeflate_amd import synth
+    rnd = random.Random(77)
+    noisy = synth.gen_stream_np(0, 65536).tobytes()
+    half = synth.gen_stream_np(15, 40000).tobytes()
+    text = (b"it was the best of times, it was the worst of times, " * 300) + bytes(rnd.randrange(256) for _ in range(5000))
+    bases = [("zlib6", zlib.compress(noisy, 6)), ("zlib1", zlib.compress(half, 1)), ("zlib9text", zlib.compress(text, 9))]
+    for strat, sname in ((zlib.Z_FIXED, "fixed"), (zlib.Z_HUFFMAN_ONLY, "huff"), (zlib.Z_RLE, "rle")):
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strat)
+        bases.append((sname, c.compress(noisy[:30000]) + c.flush()))
+    bases.append(("uf", ob.compress_ultra_fast(noisy)))
+    bases.append(("uf_half", ob.compress_ultra_fast(half)))
+    bases.append(("stored", ob.compress_stored(noisy + noisy[:5000])))
+    c = zlib.compressobj(6)
+    multi = b"".join(c.compress(noisy[k:k + 9000]) + c.flush(zlib.Z_FULL_FLUSH) for k in range(0, 63000, 9000)) + c.flush()
+    bases.append(("flushes", multi))
+    names, blobs = [], []
+    for bname, base in bases:
+        cuts = sorted(set([rnd.randrange(2, len(base)) for _ in range(24)] + list(range(len(base) - 12, len(base)))))
+        for cut in cuts:
+            names.append("%s_cut%d" % (bname, cut))
+            blobs.append(base[:cut])
+        for k in range(16):
+            b = bytearray(base)
+            at = rnd.randrange(len(b) // 2, len(b)) if k % 2 else len(b) - 1 - rnd.randrange(6)
+            b[at] ^= 1 << rnd.randrange(8)
+            names.append("%s_flip%d" % (bname, at))
+            blobs.append(bytes(b))
+    return names, blobs
+
+
+def test_damaged_long_streams_rederived_from_a_check_point(harness):
+    """inflate_general_kernel re-derives a doubtful result with the exact serial decoder from its last check
+    point (a block header or the start of a tile) instead of the stream's first byte: same status, length
+    and Adler-32 as the oracle for cuts, bit flips and damaged trailers far into long streams -- with the
+    check points (default), without them (FDH_FLAG_NO_CHECKPOINTS, 0x4000: the serial pass over the whole
+    stream of rounds 1-3), and with the LZ-window kernel out of the way (0x1000)."""
+    names, blobs = _damaged_long_cases()
+    import random
+    rnd = random.Random(3)
+    for caps in ([1 << 17] * len(blobs), [rnd.choice((65536, 40000, 30000, 12345, 1000)) for _ in blobs]):
+        # what `read` had produced when the input ran out (the streaming object relies on that length)
+        partial = {}
+        for i, blob in enumerate(blobs):
+            d = ob.Decompressor()
+            out = np.zeros(caps[i], dtype=np.uint8)
+            st, c, p = d.read(blob, out, 0)
+            if st == 0 and not d.is_done() and p < caps[i]:
+                partial[i] = out[:p].tobytes()
+        assert len(partial) > 100
+        for flags in (0, 0x4000, 0x1000, 0x1000 | 0x4000):
+            harness.assert_inflate_parity(names, blobs, caps, flags=flags)
+            st, ln, ad, outs, ok = harness.gpu_inflate(blobs, caps, flags)
+            for i, data in partial.items():
+                assert int(st[i]) == 2, (names[i], int(st[i]), flags)
+                assert int(ln[i]) == len(data) and outs[i][:len(data)].tobytes() == data, (names[i], int(ln[i]), len(data), flags)
+
+
 def test_ultrafast_encode_bit_exact(harness):
     import fdeflate_amd as fd
     r = np.random.default_rng(99)
