@@ -150,30 +150,23 @@ def encode_zlib6(raw_rows, dev):
     return torch.from_numpy(buf).to(dev), torch.from_numpy(off_h).to(dev), torch.from_numpy(clen_h).to(dev)
 
 
-def build_mix(n, raw, uf_comp, uf_off, uf_len, dev):
-    """n streams for the mix line: a pool of distinct streams tiled in a fixed shuffled order, packed back
-    to back (any alignment is accepted), exact output slots.  -> packed input, offsets, output offsets,
-    raw lengths, expectations (python's zlib is the checker here: the inflate output of a valid stream is
-    unique)."""
-    import random
+def mix_pool(raw, uf_comp, uf_off, uf_len, rnd):
+    """The distinct streams of the mix line: (compressed, raw or None, Ok expected, what it is)."""
     import zlib
-    import numpy as np
-    import torch
-    rnd = random.Random(2024)
-    pool = []   # (compressed, raw or None, Ok expected)
+    pool = []
     gold = os.path.join(ROOT, "tests", "golden", "vectors")
     nref = 0
     for name in sorted(os.listdir(os.path.join(gold, "corpus"))):
         c = open(os.path.join(gold, "corpus", name), "rb").read()
-        pool.append((c, zlib.decompress(c), True))
+        pool.append((c, zlib.decompress(c), True, "corpus/" + name))
         nref += 1
     for name in sorted(os.listdir(gold)):
         if name.endswith(".zz"):   # (a wrong checksum, two trees without an end-of-block code: reference tests/*.zz)
             c = open(os.path.join(gold, name), "rb").read()
             try:
-                pool.append((c, zlib.decompress(c), True))
+                pool.append((c, zlib.decompress(c), True, name))
             except zlib.error:
-                pool.append((c, None, False))
+                pool.append((c, None, False, name))
             nref += 1
     h = raw[:48].cpu().numpy()
     for i in range(48):
@@ -191,25 +184,39 @@ def build_mix(n, raw, uf_comp, uf_off, uf_len, dev):
             c = zlib.compress(r, 6)
         else:
             c = zlib.compress(r, 6)
-        pool.append((c, r, True))
+        pool.append((c, r, True, "zlib kind %d of buffer %d" % (kind, i)))
     ufo = uf_off[:33].cpu().numpy()
     ufl = uf_len[:32].cpu().numpy()
     ufc = uf_comp[:int(ufo[32])].cpu().numpy()
     for i in range(32):                                               # the headline's own format
-        pool.append((ufc[int(ufo[i]):int(ufo[i]) + int(ufl[i])].tobytes(), h[i].tobytes(), True))
+        pool.append((ufc[int(ufo[i]):int(ufo[i]) + int(ufl[i])].tobytes(), h[i].tobytes(), True, "ultra-fast, buffer %d" % i))
     good = [p for p in pool if p[2] and len(p[0]) > 64]
     for k in range(24):                                               # damaged and truncated copies: never Ok
-        c = good[rnd.randrange(len(good))][0]
+        g = good[rnd.randrange(len(good))]
+        c = g[0]
         if k % 3 == 0:
-            pool.append((c[:rnd.randrange(8, len(c) - 4)], None, False))   # InsufficientInput
+            pool.append((c[:rnd.randrange(8, len(c) - 4)], None, False, "cut short: " + g[3]))   # InsufficientInput
         elif k % 3 == 1:
             b = bytearray(c)
             b[len(b) - 1 - rnd.randrange(4)] ^= 1 << rnd.randrange(8)      # WrongChecksum
-            pool.append((bytes(b), None, False))
+            pool.append((bytes(b), None, False, "trailer damaged: " + g[3]))
         else:
             b = bytearray(c)
             b[0] ^= 0x07                                                   # BadZlibHeader
-            pool.append((bytes(b), None, False))
+            pool.append((bytes(b), None, False, "header damaged: " + g[3]))
+    return pool, nref
+
+
+def build_mix(n, raw, uf_comp, uf_off, uf_len, dev):
+    """n streams for the mix line: a pool of distinct streams tiled in a fixed shuffled order, packed back
+    to back (any alignment is accepted), exact output slots.  -> packed input, offsets, output offsets,
+    raw lengths, expectations (python's zlib is the checker here: the inflate output of a valid stream is
+    unique)."""
+    import random
+    import numpy as np
+    import torch
+    rnd = random.Random(2024)
+    pool, nref = mix_pool(raw, uf_comp, uf_off, uf_len, rnd)
     order = [rnd.randrange(len(pool)) for _ in range(n)]
     clen = np.array([len(pool[j][0]) for j in order], dtype=np.int64)
     rlen = np.array([len(pool[j][1]) if pool[j][1] is not None else 65536 for j in order], dtype=np.int64)

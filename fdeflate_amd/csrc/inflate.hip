@@ -31,7 +31,9 @@ namespace fdh {
 #include "uf_table_data.inc"
 
 constexpr uint32_t kPending = 0xFFFFFFFFu;         // not decoded yet, tiles allowed
-constexpr uint32_t kPendingSerial = 0xFFFFFFFEu;   // not decoded yet, serial decoder only
+constexpr uint32_t kPendingSerial = 0xFFFFFFFEu;   // not decoded yet, serial decoder only (resume[sid], when there is such an
+                                                   // array, was written by whoever set this status: valid or all zero)
+constexpr uint32_t kPendingResume = 0xFFFFFFFDu;   // not decoded to its end yet, tiles allowed: the LZ-window kernel left it at resume[sid]
 constexpr uint32_t kCanonBits = 53 * 8 + 5;        // ultrafast.rs:87-88
 constexpr int kCanonWaves = 8;
 constexpr uint64_t kLaneMinStreams = ~0ull;  // opt-in only (FDH_FLAG_FORCE_LANES): 1 wave/SIMD at 64 Ki streams is no win
@@ -83,7 +85,31 @@ struct InflateBatchArgs {
     uint32_t* lz_counter;  // hand-out counter of the LZ-window kernel (zeroed by the launcher)
     uint2* lz_ck;          // its items: 64 x kLzMaxPhases per wavefront (stream-ordered scratch)
     uint32_t* list_out;    // nullable: where the LZ-window kernel lists what it leaves ([0] = count, [4..] = ids)
+    uint4* resume;         // nullable: per stream, where a kernel left it: {bit of the block header (0: nowhere), bit to go on
+                           // from, output bytes decoded, their Adler-32} -- a ResumePoint.  Only ever read for a stream
+                           // whose status says it was written (kPendingResume, kPendingSerial): no initialisation
 };
+// The resume point a kernel in front left for stream `sid`, whose status is `st` (if any).
+__device__ __forceinline__ ResumePoint resume_point(const InflateBatchArgs& a, const uint64_t sid, const uint32_t st) {
+    ResumePoint rp;
+    rp.valid = 0;
+    rp.step = 0;
+    if (a.resume && a.only_pending && (st == kPendingResume || st == kPendingSerial) && !(a.flags & 0x4000u)) {
+        const uint4 v = a.resume[sid];
+        rp.hdr_bit = v.x & 0x3FFFFFFFu;
+        rp.step = v.x >> 30;
+        rp.bit = v.y;
+        rp.opos = v.z;
+        rp.adler = v.w;
+        rp.valid = v.x != 0 ? 1u : 0u;
+    }
+    return rp;
+}
+// (a record keeps bit positions in 30 bits: streams of 128 MiB and more go without)
+__device__ __forceinline__ uint4 resume_record(const ResumePoint& rp) {
+    const bool fits = rp.valid && rp.bit < (1ull << 30) && rp.hdr_bit != 0;
+    return fits ? make_uint4((uint32_t)rp.hdr_bit | (rp.step << 30), (uint32_t)rp.bit, rp.opos, rp.adler) : make_uint4(0, 0, 0, 0);
+}
 constexpr uint32_t kSpanSlots = 2048;  // > workgroups of the general kernel resident on one device (256 CUs x 5)
 
 __device__ __forceinline__ StreamArgs stream_args(const InflateBatchArgs& a, uint64_t sid) {
@@ -106,6 +132,11 @@ __device__ __forceinline__ StreamArgs stream_args(const InflateBatchArgs& a, uin
 __device__ __forceinline__ bool needs_serial_recheck(const StreamResult& r, uint32_t flags) {
     if (flags & 8u) return false;  // FDH_FLAG_NO_RECHECK (tests: the tile decoder on its own)
     if (r.status == ST_OK) return false;
+    // A decoder that got as far as comparing the checksum read every block to its end and found the four trailer
+    // bytes behind the last one: the input never ran short inside a token, which is the only place where the
+    // reference's pairing of literals shows (resync_to_step_start, inflate_stream.h), and the reference gets
+    // there too -- Ok or WrongChecksum is then the comparison itself (src/decompress.rs:306-326).
+    if (r.status == ST_WRONG_CHECKSUM) return false;
     if (r.status == ST_OUTPUT_TOO_LARGE || r.status == ST_INSUFFICIENT_INPUT) return r.ambiguous;
     return true;
 }
@@ -123,15 +154,19 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
     const int lane = threadIdx.x;
     if (sid >= a.n) return;
     bool tiles = !(a.flags & 2u);
+    uint32_t st = kPending;
     if (a.only_pending) {
-        uint32_t st = a.status[sid];
-        if (st != kPending && st != kPendingSerial) return;
+        st = a.status[sid];
+        if (st != kPending && st != kPendingSerial && st != kPendingResume) return;
     }
     const StreamArgs s = stream_args(a, sid);
     Inflater inf(lds.tables, lds.io, &lds.hs, lane);
     StreamResult r;
-    ResumePoint rp;
-    rp.valid = 0;
+    const ResumePoint rec = resume_point(a, sid, st);  // where a kernel in front left the stream
+    ResumePoint rp = rec;
+    // A tile decoder in front has been over this stream and left it at its last check point for the exact
+    // serial decoder: no second pass of tiles.
+    if (st == kPendingSerial && rec.valid) tiles = false;
     if (tiles) {
         // the span decoder lists matches in global scratch: take one of the pool's slots
         uint32_t slot = kSpanSlots;
@@ -143,14 +178,14 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
             slot = uni(slot);
             inf.span_list = a.span_pool + kSpanSlots + (size_t)slot * (2 * kSpanMaxMatches);
         }
-        // The tiles of this kernel follow the reference's own chain of table steps (12-bit tables, its pairing
-        // of literals), so the state in front of a tile is a state the reference passes through: check points
-        // are taken there, and a result the tiles may have classified differently is re-derived by the exact
-        // serial decoder from the last of them -- the tail of the stream, not the stream (round 3: a damaged
-        // stream cost a serial pass over all of it).
+        // Check points are taken at every block header and in front of every tile, and a result the tiles may
+        // have classified differently from the reference is re-derived by the exact serial decoder from the last
+        // of them -- the tail of the stream, not the stream (rounds 1-3: a damaged stream cost a serial pass over
+        // all of it).  A tile starts at a symbol, not necessarily at one of the reference's table steps:
+        // resync_to_step_start (inflate_stream.h) deals with that.
         inf.keep_ck = !(a.flags & 0x4000u);
         inf.init(s);
-        r = inf.run<true, false>();
+        r = rec.valid ? inf.run_from<true>(rec) : inf.run<true, false>();
         if (slot < kSpanSlots) {
             __threadfence();
             if (lane == 0) atomicExch(&a.span_pool[slot], 0u);
@@ -159,7 +194,7 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
         inf.keep_ck = false;
         if (needs_serial_recheck(r, a.flags)) {
             tiles = false;
-            rp = inf.ck;
+            if (inf.ck.valid) rp = inf.ck;
         }
     }
     if (!tiles) {
@@ -217,19 +252,24 @@ static_assert(sizeof(HeaderScratch) <= sizeof(WaveIo::mlist) && offsetof(WaveIo,
 __device__ __forceinline__ void general_fast_one(const InflateBatchArgs& a, GeneralFastLds& lds, const uint64_t sid) {
     const int lane = threadIdx.x;
     if (sid >= a.n) return;
-    if (a.only_pending && a.status[sid] != kPending) return;
+    uint32_t st = kPending;
+    if (a.only_pending) {
+        st = a.status[sid];
+        if (st != kPending && st != kPendingResume) return;
+    }
     const StreamArgs s = stream_args(a, sid);
     InflaterT<kFastLitBits, false> inf(lds.tables, lds.io, reinterpret_cast<HeaderScratch*>(lds.io.mlist), lane);
+    inf.keep_ck = a.resume != nullptr && !(a.flags & 0x4000u);  // (what it cannot classify goes on from its last check point)
     inf.init(s);
-    const StreamResult r = inf.run<true, false>();
-    if (lane == 0) {
-        if (needs_serial_recheck(r, a.flags)) {
-            a.status[sid] = kPendingSerial;
-        } else {
-            a.status[sid] = r.status;
-            a.out_len[sid] = r.out_len;
-            if (a.adler) a.adler[sid] = r.adler;
-        }
+    const ResumePoint rec = resume_point(a, sid, st);
+    const StreamResult r = rec.valid ? inf.run_from<true>(rec) : inf.run<true, false>();
+    if (needs_serial_recheck(r, a.flags)) {
+        if (a.resume && lane == 0) a.resume[sid] = resume_record(inf.ck.valid ? inf.ck : rec);
+        if (lane == 0) a.status[sid] = kPendingSerial;
+    } else if (lane == 0) {
+        a.status[sid] = r.status;
+        a.out_len[sid] = r.out_len;
+        if (a.adler) a.adler[sid] = r.adler;
     }
 }
 __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_general_fast_kernel(InflateBatchArgs a) {
@@ -249,8 +289,9 @@ __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_genera
 
 // LZ-window kernel (inflate_lz.h): any stream of Huffman blocks, the history in LDS.  One wavefront =
 // one workgroup = one stream at a time, four per CU.  Returns true when the stream is finished (Ok).
-__device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, const uint64_t sid) {
+__device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, const uint64_t sid, uint4& rec) {
     const int lane = threadIdx.x;
+    rec = make_uint4(0, 0, 0, 0);  // (header bit 0: no resume point)
     if (sid >= a.n) return false;
     if (a.only_pending) {  // finished by a kernel in front: nothing to do; left for the exact serial decoder: not ours
         const uint32_t st = a.status[sid];
@@ -280,27 +321,39 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     o.flushed = 0;
     o.adler_a = 1;
     o.adler_b = 0;
-    uint32_t bitpos = 16;
+    uint32_t bitpos = 16, hdr_bit = 16;
     bool fixed_built = false;
+    // This kernel gives up on the stream at stream bit `bit` of the block whose header starts at hdr_bit (bit ==
+    // hdr_bit: at the header itself): everything in front of it is decoded, so it all goes to the slot with its
+    // checksum and the kernels behind take the stream up there instead of at its first byte.
+    auto leave = [&](const uint32_t bit) __attribute__((always_inline)) -> bool {
+        if (o.O != 0 && !(a.flags & 0x4000u)) {
+            lz_flush(L, o, true, lane);
+            rec = make_uint4(hdr_bit, bit, o.O, (o.adler_b << 16) | o.adler_a);
+        }
+        return false;
+    };
 #ifdef FDH_LZ_DEBUG
     o.tq = clock64();
 #endif
+    uint32_t eob_bits = 0;
     for (;;) {  // blocks
+        hdr_bit = bitpos;
         inf.refill();
-        if (inf.left < 10) return false;
+        if (inf.left < 10) return leave(hdr_bit);
         const uint32_t type = ((uint32_t)inf.bb >> 1) & 3;
-        if (type == 0 || type == 3) return false;  // stored blocks: the kernels behind
+        if (type == 0 || type == 3) return leave(hdr_bit);  // stored blocks: the kernels behind
         uint32_t rc = RC_OK;
         inf.last_block = ((uint32_t)inf.bb & 1) != 0;
         if (type == 2) {  // dynamic: this kernel's own parser and table builder
-            if (inf.left < 17) return false;
+            if (inf.left < 17) return leave(hdr_bit);
             const uint32_t hlit = (((uint32_t)inf.bb >> 3) & 31) + 257, hdist = (((uint32_t)inf.bb >> 8) & 31) + 1;
             const uint32_t hclen = (((uint32_t)inf.bb >> 13) & 15) + 4;
-            if (hlit > 286 || hdist > 30) return false;
+            if (hlit > 286 || hdist > 30) return leave(hdr_bit);
             inf.consume(17);
             fixed_built = false;
             LZT(o, 0);
-            if (!lz_parse_dynamic(L, inf, hlit, hdist, hclen, lane, o)) return false;
+            if (!lz_parse_dynamic(L, inf, hlit, hdist, hclen, lane, o)) return leave(hdr_bit);
             lz_build_sub(L, lane);
             LZT(o, 17);
         } else {  // fixed: the same builder on the lengths of src/tables.rs:207-232 (an empty block is one end-of-block token)
@@ -312,7 +365,7 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
                     const uint32_t sy = (uint32_t)lane + 64u * k;
                     ll[k] = sy < 144 ? 8u : sy < 256 ? 9u : sy < 280 ? 7u : sy < 288 ? 8u : 0u;
                 }
-                if (!lz_build_tables(L, ll, lane < 32 ? 5u : 0u, lane, o)) return false;
+                if (!lz_build_tables(L, ll, lane < 32 ? 5u : 0u, lane, o)) return leave(hdr_bit);
                 lz_build_sub(L, lane);
                 fixed_built = true;
             }
@@ -324,11 +377,12 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
         if (rc == RC_OK) {
             uint32_t qcap = kLzRange;
             for (uint32_t nspans = 0;; nspans++) {  // super-spans
-                if (bitpos >= in_bits || nspans > in_bits) return false;
-                const uint32_t res = lz_superspan(L, o, bd, lin, bitpos, qcap, lane);
-                if (res == LZ_BAIL) return false;
+                if (bitpos >= in_bits || nspans > in_bits) return leave(bitpos);
+                const uint32_t res = lz_superspan(L, o, bd, lin, bitpos, eob_bits, qcap, lane);
+                if (res == LZ_DISTRUST) return false;
+                if (res == LZ_BAIL) return leave(bitpos);
                 if (res == LZ_SHRINK) {  // an item that does not fit an image: shorter phases from there on
-                    if (qcap <= 8) return false;
+                    if (qcap <= 8) return leave(bitpos);
                     qcap = max(8u, qcap / 4);
                     continue;
                 }
@@ -336,17 +390,18 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
             }
         }
         // back to the wave-serial reader (its window shares LDS with the span's stage: reload)
-        if (bitpos > in_bits) return false;
+        if (bitpos > in_bits) return leave(bitpos - eob_bits);
         inf.left = in_bits - bitpos;
         inf.loaded = 0x7FFFFFF0u;
         inf.seek(bitpos);
         if (last) break;
     }
+    // (a trailer that is cut short or wrong: the exact kernels take the stream up at the last end-of-block code)
     uint32_t stored = 0;
-    if (inf.read_trailer(stored) != RC_OK) return false;
+    if (inf.read_trailer(stored) != RC_OK) return leave(bitpos - eob_bits);
     lz_flush(L, o, true, lane);
     const uint32_t adler = (o.adler_b << 16) | o.adler_a;
-    if (!(a.flags & 1u) && stored != adler) return false;  // WrongChecksum is the exact kernels' verdict
+    if (!(a.flags & 1u) && stored != adler) return leave(bitpos - eob_bits);  // WrongChecksum is the exact kernels' verdict
     if (lane == 0) {
         a.status[sid] = ST_OK;
         a.out_len[sid] = o.O;
@@ -371,11 +426,16 @@ void inflate_lz_kernel(InflateBatchArgs a) {
     const uint32_t cnt = a.list[0];
     for (uint32_t i = blockIdx.x; i < cnt;) {
         const uint32_t sid = a.list[4 + i];
-        const bool finished = lz_one(a, lds, sid);
+        uint4 rec;
+        const bool finished = lz_one(a, lds, sid, rec);
         wave_sync();
         if (threadIdx.x == 0) {
             // what this kernel leaves goes on a list of its own: the kernels behind do not look at the rest
             if (!finished && a.list_out) a.list_out[4 + atomicAdd(&a.list_out[0], 1u)] = sid;
+            if (!finished && a.resume && rec.x != 0) {  // where the kernels behind take the stream up
+                a.resume[sid] = rec;
+                a.status[sid] = kPendingResume;
+            }
             i = atomicAdd(a.lz_counter, 1u) + gridDim.x;
         }
         i = uni(i);
@@ -443,9 +503,12 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
     inf.eof_code = lds.tables.eof[0];
     inf.eof_mask = lds.tables.eof[1];
     inf.eof_bits = lds.tables.eof[2];
+    inf.hdr_bit = 16;  // (the block header of the prefix, for the check points)
+    inf.keep_ck = a.resume != nullptr && !(a.flags & 0x4000u);
     StreamResult r = inf.run<true, true>();
     if (lane == 0) {
         if (needs_serial_recheck(r, a.flags)) {
+            if (a.resume) a.resume[sid] = resume_record(inf.ck);
             a.status[sid] = kPendingSerial;
         } else {
             a.status[sid] = r.status;
@@ -804,7 +867,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
         int ordinal = 0;
         if (hipGetDevice(&ordinal) == hipSuccess && ordinal >= 0 && ordinal < 64) {
@@ -860,7 +923,9 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         const size_t ckpt_bytes = seg2 ? (size_t)s2blocks * fdh::kS2Waves * fdh::kS2CkptPerWave * sizeof(uint2) : 0;
         const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);  // LZ-window kernel: persistent wavefronts
         const size_t lzck_bytes = (flags & 0x1000u) ? 0 : (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
-        if (hipMallocAsync(reinterpret_cast<void**>(&list), list_words * sizeof(uint32_t) + ckpt_bytes + lzck_bytes, stream) != hipSuccess) {
+        const size_t resume_bytes = (size_t)n * sizeof(uint4);  // where a kernel leaves a stream for the kernels behind it
+        const size_t words_al = (list_words + 3) & ~(size_t)3;  // (what follows the lists is 16-byte aligned)
+        if (hipMallocAsync(reinterpret_cast<void**>(&list), words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes + resume_bytes, stream) != hipSuccess) {
             (void)hipGetLastError();
             list = nullptr;  // fall back to the status-scan form
         } else {
@@ -874,7 +939,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         fdh::SegArgs sa{in, in_off, out, out_off, out_len, status, adler, n, flags, canon->lit, canon->len4, canon->hdr,
                         fdh::kCanonBits, fdh::kPending, list, nullptr, nullptr, canon->nl, canon->lit2, nullptr, nullptr};
         if (list && seg2) {  // interval kernel first; what it leaves goes through the segment kernel
-            sa.ckpt = reinterpret_cast<uint2*>(list + list_words);
+            sa.ckpt = reinterpret_cast<uint2*>(list + words_al);
             sa.list2 = list + list2_at;
             if (ordered) {
                 uint32_t* order = list + list2_at + (n + 4);
@@ -920,6 +985,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         }
         if (list) {
             a.list = sa.list;
+            a.resume = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes);
             unsigned cblocks = (unsigned)((n + fdh::kCanonWaves - 1) / fdh::kCanonWaves);
             hipLaunchKernelGGL(fdh::inflate_canon_kernel, dim3(cblocks), dim3(fdh::kCanonWaves * fdh::kWave), 0, stream, a);
             e = hipGetLastError();
@@ -928,7 +994,8 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 4096);  // persistent workgroups (16 per CU at most)
             if (e == hipSuccess && !(flags & 0x1000u)) {  // the LZ-window kernel: persistent wavefronts, FDH_LZ_WAVES_PER_CU per CU
                 a.lz_counter = list + (n + 4) + 2;  // (a spare word of stream_order_kernel's counters, zeroed above)
-                a.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + list_words * sizeof(uint32_t) + ckpt_bytes);
+                a.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes);
+
                 // its leftovers: the list region the kernels in front are done with
                 a.list_out = (sa.list == list) ? list + list2_at : list;
                 e = hipMemsetAsync(a.list_out, 0, 4 * sizeof(uint32_t), stream);

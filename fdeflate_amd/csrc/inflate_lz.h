@@ -479,7 +479,8 @@ __device__ __forceinline__ LzWalk lz_walk(LzLds& L, const LzBounds& bd, uint32_t
         }
     }
     if (dbad) trouble = true;
-    if (pos > limit && stop == 0 && active) stop = 2;  // ran past the end of the input (zeros are staged there)
+    // ran past the end of the input (zeros are staged there) -- an end-of-block code found in those zeros is none
+    if (active && (pos > limit || (stop == 1 && pos + stop_bits > limit))) stop = 2;
     w.e = pos;
     w.cnt = cnt;
     w.nm = nm;
@@ -1070,7 +1071,7 @@ __device__ __forceinline__ void lz_batch_fill(LzLds& L, const LzBatch& B, const 
     wave_sync();
 }
 
-enum : uint32_t { LZ_MORE = 0, LZ_EOB = 1, LZ_BAIL = 2, LZ_SHRINK = 3 };
+enum : uint32_t { LZ_MORE = 0, LZ_EOB = 1, LZ_BAIL = 2, LZ_SHRINK = 3, LZ_DISTRUST = 4 };
 
 struct LzIn {
     const uint8_t* base16;  // 16-B aligned address at or below the stream's first byte
@@ -1096,11 +1097,15 @@ struct LzIn {
 //   items    lane-major order is stream order; 64 items at a time (as many as fit the image): offsets by prefix
 //            sums, pass 2 (every lane walks one item), resolve, flush.
 //
-// LZ_MORE / LZ_EOB: `bitpos` advanced, everything decoded is resolved, flushed and part of the history.
+// LZ_MORE / LZ_EOB: `bitpos` advanced (LZ_EOB: behind the end-of-block code of `eob_bits` bits), everything decoded
+// is resolved, flushed and part of the history.
 // LZ_SHRINK: the item at `bitpos` (advanced to it) does not fit an image: again with a smaller Q.
-// LZ_BAIL: this stream is for the exact kernels.
+// LZ_BAIL: this stream is for the exact kernels -- from `bitpos` on: what lies in front of it (possibly advanced: the
+// lanes in front of a bad token or of the end of the input, the images that fit the slot) is decoded, resolved and
+// flushed like the rest, so the kernels behind can take the stream up there (ResumePoint, inflate_stream.h).
+// LZ_DISTRUST: the two passes disagree (a bug): nothing of this stream is to be used.
 __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBounds& bd, const LzIn& in, uint32_t& bitpos,
-                                                 const uint32_t qcap, const int lane) {
+                                                 uint32_t& eob_bits, const uint32_t qcap, const int lane) {
     const uint32_t mis8 = in.mis * 8;
     const uint32_t w0 = bitpos + mis8, limit = in.in_bits + mis8;  // window bits
     const uint32_t fair = (limit - w0 + kWave - 1) / kWave;
@@ -1207,9 +1212,11 @@ __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBou
     LZC(o, 21, iters);
     LZC(o, 23, slows);
     if (!converged || __any(trouble)) return LZ_BAIL;
-    const int nvalid = first_stop < kWave ? first_stop + 1 : kWave;
     const uint32_t fs_kind = first_stop < kWave ? __builtin_amdgcn_readlane(stop, first_stop) : 0u;
-    if (fs_kind == 2) return LZ_BAIL;  // a bad token on the real chain
+    // a bad token on the real chain, or the end of the input: the lanes in front of that one are decoded all the same
+    const bool bad_end = fs_kind == 2;
+    const int nvalid = first_stop < kWave ? (bad_end ? first_stop : first_stop + 1) : kWave;
+    if (nvalid == 0) return LZ_BAIL;
     const uint32_t end_pos = __builtin_amdgcn_readlane(e, nvalid - 1);
     const uint32_t end_bits = fs_kind == 1 ? __builtin_amdgcn_readlane(stop_bits, nvalid - 1) : 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1235,7 +1242,10 @@ __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBou
             return LZ_SHRINK;
         }
         const uint32_t N = __builtin_amdgcn_readlane(incl, nuse - 1), nmatch = __builtin_amdgcn_readlane(incl_m, nuse - 1);
-        if (N > in.cap - o.O) return LZ_BAIL;  // OutputTooLarge is the exact kernels' business
+        if (N > in.cap - o.O) {  // OutputTooLarge is the exact kernels' business: from this image on
+            bitpos = __builtin_amdgcn_readfirstlane(item.x) - mis8;
+            return LZ_BAIL;
+        }
         raw_next = load_item(t + (uint32_t)nuse);
         LZT(o, 4);
         // ---- pass 2 ----
@@ -1251,7 +1261,11 @@ __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBou
             const LzWalk w2 = lz_walk<true>(L, bd, item.x, end, false, mine, limit, dw, incl - cnt, o.o_ri, o.O, incl_m - nm, trouble, &it2, &sl2);
             LZC(o, 20, it2);
             LZC(o, 22, sl2);
-            if (__any((mine && (w2.cnt != cnt || w2.nm != nm)) || trouble)) return LZ_BAIL;  // the passes disagree: a bug, never publish
+            if (__any(mine && (w2.cnt != cnt || w2.nm != nm))) return LZ_DISTRUST;  // the passes disagree: a bug, never publish
+            if (__any(trouble)) {  // a distance beyond the start of the output: the exact kernels report it, from this image on
+                bitpos = __builtin_amdgcn_readfirstlane(item.x) - mis8;
+                return LZ_BAIL;
+            }
         }
         wave_sync();
         LZT(o, 5);
@@ -1290,7 +1304,8 @@ __device__ __forceinline__ uint32_t lz_superspan(LzLds& L, LzOut& o, const LzBou
         t0 += (uint32_t)nuse;
     }
     bitpos = end_pos + end_bits - mis8;
-    return fs_kind == 1 ? LZ_EOB : LZ_MORE;
+    eob_bits = end_bits;
+    return bad_end ? LZ_BAIL : (fs_kind == 1 ? LZ_EOB : LZ_MORE);
 }
 
 }  // namespace fdh

@@ -92,7 +92,11 @@ struct ResumePoint {
     uint32_t opos;
     uint32_t adler;
     uint32_t valid;
+    uint32_t step;     // what `bit` is to the reference's chain of table steps (STEP_*): resync_to_step_start
 };
+// A symbol boundary inside a block, seen from the reference's chain of table steps (one symbol, or two literals
+// whose codes fit the table index together): the start of a step, the second literal of a pair, or not known.
+enum : uint32_t { STEP_UNKNOWN = 0, STEP_START = 1, STEP_SECOND = 2 };
 
 enum : uint32_t { RC_OK = 0, RC_EOB = 0x100, RC_STUCK = 0x101, RC_REDO = 0x102 };  // anything else: a StreamStatus
 
@@ -202,6 +206,8 @@ struct InflaterT {
     bool keep_ck;            // take a check point at every block header and in front of every tile
     uint64_t hdr_bit;        // where the current block's header starts
     ResumePoint ck;          // the last check point
+    uint32_t step_state;     // STEP_*: the current position in the reference's chain of table steps (kept while keep_ck)
+    bool last_was_pair;      // serial_token: the table entry it took was a pair of literals
 #ifdef FDH_DEBUG_TILES
     unsigned long long gacc[24] = {};
 #endif
@@ -411,6 +417,8 @@ struct InflaterT {
         span_credit = 0;
         hdr_bit = 0;
         ck.valid = 0;
+        step_state = STEP_UNKNOWN;
+        last_was_pair = false;
         seek(0);
     }
 
@@ -425,17 +433,19 @@ struct InflaterT {
         ck.opos = opos;
         ck.adler = (adler_b << 16) | adler_a;
         ck.valid = 1;
+        ck.step = ck.bit == ck.hdr_bit ? (uint32_t)STEP_START : step_state;
     }
     __device__ __forceinline__ void seek_to(uint64_t bit) {
         seek(bit);
         left = (win_bytes - mis) * 8 - bit;
     }
-    // The last kOutRing - 16 bytes of the output (or all of it) from the slot into the ring: the history of a
-    // decoder that starts at a resume point.
+    // The last kOutRing bytes of the output (or all of it) from the slot into the ring: the history of a decoder
+    // that starts at a resume point (copy_bytes reads a source from the ring when it is less than kOutRing bytes
+    // in front of the END of the copy: all of them have to be there).
     __device__ __forceinline__ void reload_out_ring() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-        const uint32_t lo_p = opos > (uint32_t)(kOutRing - 16) ? opos - (kOutRing - 16) : 0;
+        const uint32_t lo_p = opos > (uint32_t)kOutRing ? opos - kOutRing : 0;
         const uint8_t* const g = out_al + gmis;
         for (uint32_t p = lo_p + (uint32_t)lane; p < opos; p += kWave)
             io.out_ring[(p + gmis) & kOutMask] = __hip_atomic_load(g + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -582,6 +592,7 @@ struct InflaterT {
         }
         if (kind == K_LIT2) {
             if (left < nb) return RC_STUCK;
+            last_was_pair = true;
             put_byte((e >> 8) & 0xFF);
             consume(nb);
             if (opos == cap) return RC_STUCK;  // second literal queued, :866-876
@@ -662,7 +673,26 @@ struct InflaterT {
     // with serial_token); RC_EOB: the block ended; RC_REDO: the stream ended, the slot filled up or an error
     // turned up while the position was in doubt -- the caller decodes from the first byte, as rounds 1-3 did
     // for every such stream; anything else: a result met at the start of a step, exact.
-    __device__ __forceinline__ uint32_t resync_to_step_start() {
+    __device__ __forceinline__ uint32_t resync_to_step_start(const uint32_t known) {
+        if (known == STEP_START) return RC_OK;
+        if (known == STEP_SECOND) {
+            // The second literal of a pair.  The reference takes the pair in one step when all its bits are there,
+            // and nothing of it otherwise (:852) -- then the first literal, already in the output, was one too
+            // many.  (A code found within the bits that are left is the real one: no code is a prefix of another.)
+            if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack - 264)) flush(false);
+            refill();
+            const uint32_t e = uni(T.lit[(uint32_t)bb & (kLSize - 1)]);
+            const uint32_t kind = (e >> 4) & 15;
+            const uint32_t n2 = kind == K_LIT2 ? (e >> 24) : (e & 15);
+            if ((kind != K_LIT1 && kind != K_LIT2) || left < n2) {
+                opos -= 1;
+                return RC_STUCK;
+            }
+            if (opos == cap) return RC_STUCK;  // the pair is taken, its second literal queued (:866-876): the slot is full
+            put_byte((e >> 8) & 0xFF);
+            consume(n2);
+            return RC_OK;
+        }
         for (;;) {
             if (opos - flushed > (uint32_t)(kOutRing - kFlushSlack - 264)) flush(false);
             refill();
@@ -904,6 +934,15 @@ struct InflaterT {
         TPHASE(12);
         // ---- emit literals, list matches ----
         wave_sync();
+        // With check points (and the reference's own tables, LB = 12) the tile also follows the reference's chain
+        // of table steps through its symbols: a symbol whose table entry is a pair of literals is the first half
+        // of a step when a step starts at it (the next symbol is then a second half, and a step starts behind
+        // that one whatever ITS entry says); any other symbol is a step of its own.  Per symbol that is either
+        // "swap" (pair entry) or "reset to: a step starts behind it"; a lane composes its symbols, the wavefront
+        // its lanes (below).
+        const bool track = keep_ck && LB == kLitBits;
+        bool lane_reset = false;
+        uint32_t lane_flip = 0;
         if (emit) {
             uint64_t m = mask;
             uint32_t opo = opos + obase + gmis;
@@ -917,12 +956,32 @@ struct InflaterT {
                     io.out_ring[opo & kOutMask] = (uint8_t)(e >> 8);
                     opo++;
                     uint32_t n1 = e >> 24;
+                    if (k == K_LIT2) {
+                        lane_flip ^= 1u;
+                    } else {
+                        lane_reset = true;
+                        lane_flip = 0;
+                    }
                     if (k == K_LIT2 && p + n1 < (uint32_t)kTileBits) {
                         io.out_ring[opo & kOutMask] = (uint8_t)(e >> 16);
                         opo++;
                         m &= ~(1ull << (p + n1));
+                        // the second literal's own entry: does it pair with what follows?  (A chain that was followed
+                        // symbol by symbol may have stopped AT the second literal -- its own pair does not fit the input --
+                        // then the byte written above lies behind the tile's output and the symbol is not part of the tile.)
+                        if (track && ((mask >> (p + n1)) & 1)) {
+                            const uint32_t e2 = T.lit[bits32(p + n1) & (kLSize - 1)];
+                            if (((e2 >> 4) & 15) == K_LIT2) {
+                                lane_flip ^= 1u;
+                            } else {
+                                lane_reset = true;
+                                lane_flip = 0;
+                            }
+                        }
                     }
                 } else {  // match
+                    lane_reset = true;
+                    lane_flip = 0;
                     uint32_t lcb = e & 15, lex = (e >> 8) & 31;
                     uint32_t length = (e >> 16) + (bits32(p + lcb) & ((1u << lex) - 1));
                     uint32_t dv = bits32(p + lcb + lex);
@@ -935,6 +994,17 @@ struct InflaterT {
                     opo += length;
                 }
             }
+        }
+        if (track) {
+            const uint64_t R = __ballot(emit && lane_reset), F = __ballot(emit && lane_flip != 0);
+            if (R) {
+                const int lr = 63 - __builtin_clzll((unsigned long long)R);
+                step_state = (__popcll(F & ~((1ull << lr) - 1)) & 1) ? (uint32_t)STEP_SECOND : (uint32_t)STEP_START;
+            } else if (step_state != STEP_UNKNOWN && (__popcll(F) & 1)) {
+                step_state = step_state == STEP_START ? (uint32_t)STEP_SECOND : (uint32_t)STEP_START;
+            }
+        } else {
+            step_state = STEP_UNKNOWN;
         }
         wave_sync();
         TPHASE(13);
@@ -1250,21 +1320,7 @@ struct InflaterT {
     // The last kOutRing bytes of output back into the output ring (history of later matches), by
     // whole 16-B lines of the slot's address space; what lies outside [.., opos) is never read.
     // Everything up to opos must be in the slot (flushed == opos).
-    __device__ __forceinline__ void span_reload_out_ring() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
-        const uint32_t lo_p = opos > (uint32_t)(kOutRing - 16) ? opos - (kOutRing - 16) : 0;
-        for (uint32_t lq = ((lo_p + gmis) & ~15u) + (uint32_t)lane * 16; lq < opos + gmis; lq += kWave * 16) {
-            const uint32_t* lp = reinterpret_cast<const uint32_t*>(out_al + lq);
-            uint4 v;
-            v.x = __hip_atomic_load(lp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.y = __hip_atomic_load(lp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.z = __hip_atomic_load(lp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.w = __hip_atomic_load(lp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *reinterpret_cast<uint4*>(&io.out_ring[lq & kOutMask]) = v;
-        }
-        wave_sync();
-    }
+    __device__ __forceinline__ void span_reload_out_ring() { reload_out_ring(); }
     __device__ __forceinline__ uint32_t span_step(uint32_t& progress) {
         progress = 0;
         const uint64_t P64 = consumed_bits();
@@ -1627,6 +1683,7 @@ struct InflaterT {
                 GSTAT(4, progress);
                 GSTAT(7, clock64() - ts);
 #endif
+                step_state = STEP_UNKNOWN;  // (spans do not keep track of the reference's steps)
                 if (rc != RC_OK) return rc;
                 if (progress) continue;
                 if (span_credit == 0) span_credit = 8;
@@ -1654,7 +1711,10 @@ struct InflaterT {
             const long long t1 = clock64();
             const uint64_t c0 = consumed_bits();
 #endif
+            last_was_pair = false;
             uint32_t rc = serial_token();
+            // (from the start of a step it took a step; from anywhere else a symbol that pairs with nothing puts it in step)
+            if (step_state != STEP_START) step_state = last_was_pair ? (uint32_t)STEP_UNKNOWN : (uint32_t)STEP_START;
 #ifdef FDH_DEBUG_TILES
             (void)t1;
             (void)c0;
@@ -1722,8 +1782,10 @@ struct InflaterT {
                 GSTAT(8, clock64() - th);
                 GSTAT(9, 1);
 #endif
+                step_state = STEP_START;
                 if (rc == RC_OK) rc = decode_block_data<TILES>();
             } else {
+                step_state = STEP_START;
                 rc = decode_block_data<TILES>();
             }
             if (rc != RC_EOB) break;  // stuck or error
@@ -1753,10 +1815,19 @@ struct InflaterT {
             hdr_bit = consumed_bits();
             if (keep_ck && !first) take_ck();
             rc = parse_block_header();
+            step_state = STEP_START;
             if (rc == RC_OK) {
                 if (first && rp.bit != rp.hdr_bit) {
                     seek_to(rp.bit);
-                    rc = resync_to_step_start();
+                    // (with tiles the result is only final when it does not depend on the pairing: see needs_serial_recheck)
+                    step_state = rp.step;
+#ifdef FDH_DEBUG_STEP
+                    if (lane == 0) printf("resume bit %llu opos %u step %u left %llu\n", (unsigned long long)rp.bit, rp.opos, rp.step, (unsigned long long)left);
+#endif
+                    if (!TILES) {
+                        rc = resync_to_step_start(rp.step);
+                        step_state = STEP_START;
+                    }
                     if (rc == RC_REDO) {
                         StreamResult r;
                         r.status = RC_REDO;
