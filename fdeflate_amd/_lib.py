@@ -37,6 +37,8 @@ def lib():
     L.fdh_ultrafast_bound.argtypes = [u64]
     L.fdh_inflate_batch.restype = C.c_int
     L.fdh_inflate_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, u32, vp]
+    L.fdh_inflate_batch_resumable.restype = C.c_int
+    L.fdh_inflate_batch_resumable.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, u32, vp, vp]
     pp = C.POINTER(C.c_void_p)
     L.fdh_deflate_ultrafast_batch.restype = C.c_int
     L.fdh_deflate_ultrafast_batch.argtypes = [vp, vp, vp, vp, vp, u64, vp]
@@ -89,6 +91,8 @@ def lib():
     L.fdh_decompressor_is_done.restype = C.c_int
     L.fdh_decompressor_attempts.argtypes = [vp]
     L.fdh_decompressor_attempts.restype = C.c_uint64
+    L.fdh_decompressor_decoded_bytes.argtypes = [vp]
+    L.fdh_decompressor_decoded_bytes.restype = C.c_uint64
     L.fdh_decompressor_read.restype = C.c_int
     L.fdh_decompressor_read.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]
     _lib = L
@@ -97,11 +101,11 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "fdh_version", "fdh_status_name", "fdh_last_error", "fdh_device_count", "fdh_ultrafast_bound",
-    "fdh_inflate_batch", "fdh_deflate_ultrafast_batch", "fdh_debug_build_tables",
+    "fdh_inflate_batch", "fdh_inflate_batch_resumable", "fdh_deflate_ultrafast_batch", "fdh_debug_build_tables",
     "fdh_decompress_to_vec", "fdh_decompress_to_vec_bounded", "fdh_compress_to_vec_ultra_fast",
     "fdh_free", "fdh_stored_size", "fdh_deflate_stored_batch", "fdh_compress_to_vec_stored",
     "fdh_decompressor_new", "fdh_decompressor_free", "fdh_decompressor_ignore_adler32",
-    "fdh_decompressor_is_done", "fdh_decompressor_read", "fdh_decompressor_attempts",
+    "fdh_decompressor_is_done", "fdh_decompressor_read", "fdh_decompressor_attempts", "fdh_decompressor_decoded_bytes",
     "fdh_compress_bound", "fdh_deflate_general_batch", "fdh_compress_to_vec", "fdh_compress_to_vec_rle",
     "fdh_png_unfilter_batch", "fdh_png_filter_batch", "fdh_inflate_png_batch", "fdh_png_filter_deflate_ultrafast_batch",
     "fdh_init", "fdh_shutdown", "fdh_multi_device_count", "fdh_multi_uses_rccl", "fdh_inflate_batch_multi",

@@ -86,6 +86,10 @@ class Decompressor:
         """Decode attempts made so far (introspection, fdh_decompressor_attempts)."""
         return int(self._L.fdh_decompressor_attempts(self._d))
 
+    def decoded_bytes(self):
+        """Output bytes decoded by all attempts together (introspection, fdh_decompressor_decoded_bytes)."""
+        return int(self._L.fdh_decompressor_decoded_bytes(self._d))
+
     def read(self, data, output, output_position):
         data = bytes(data)
         mv = memoryview(output)
@@ -266,6 +270,28 @@ def inflate_batch(comp, in_off, out, out_off, out_len=None, status=None, adler=N
         _lib.check(_lib.lib().fdh_inflate_batch(_ptr(comp), _ptr(in_off), _ptr(out), _ptr(out_off),
                                                _ptr(out_len), _ptr(status), _ptr(adler), n, flags,
                                                C.c_void_p(stream)))
+    return out_len, status, adler
+
+
+def inflate_batch_resumable(comp, in_off, out, out_off, resume, out_len=None, status=None, adler=None, flags=0, resume_in=False):
+    """fdh_inflate_batch_resumable: as inflate_batch; `resume` (int32 [n, 4] on the device) receives, for every
+    stream that ended InsufficientInput / OutputTooLarge, the place from which a later call can go on, and with
+    resume_in says where each stream is taken up in this call (the slots then hold the output so far)."""
+    import torch
+    n = in_off.numel() - 1
+    dev = comp.device
+    if out_len is None:
+        out_len = torch.empty(n, dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.empty(n, dtype=torch.int32, device=dev)
+    if adler is None:
+        adler = torch.empty(n, dtype=torch.int32, device=dev)
+    assert resume.dtype == torch.int32 and resume.numel() == 4 * n and resume.is_contiguous()
+    with _OnDevice(comp, in_off, out, out_off, out_len, status, adler, resume) as stream:
+        _lib.check(_lib.lib().fdh_inflate_batch_resumable(_ptr(comp), _ptr(in_off), _ptr(out), _ptr(out_off),
+                                                         _ptr(out_len), _ptr(status), _ptr(adler), n,
+                                                         flags | (0x8000 if resume_in else 0), _ptr(resume),
+                                                         C.c_void_p(stream)))
     return out_len, status, adler
 
 

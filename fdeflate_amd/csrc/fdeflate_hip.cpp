@@ -15,7 +15,7 @@
 extern "C" {
 int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                        uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
-                       hipStream_t stream);
+                       void* resume_io, hipStream_t stream);
 int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status);
 int fdh_launch_build_tables_debug(const uint8_t* code_lengths, uint32_t hlit, uint32_t* litlen, uint32_t* dist,
                                   uint32_t* build_status, hipStream_t stream);
@@ -150,8 +150,22 @@ int fdh_inflate_batch(const uint8_t* in, const uint64_t* in_off, uint8_t* out, c
     if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
     int rc = ensure_canon_tables(static_cast<hipStream_t>(hip_stream));
     if (rc != FDH_SUCCESS) return rc;
-    rc = fdh_launch_inflate(in, in_off, out, out_off, out_len, status, adler, n, flags,
+    rc = fdh_launch_inflate(in, in_off, out, out_off, out_len, status, adler, n, flags & ~FDH_FLAG_RESUME_IN, nullptr,
                             static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "inflate kernel launch");
+    return FDH_SUCCESS;
+}
+
+int fdh_inflate_batch_resumable(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                                uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
+                                fdh_resume_point* resume, void* hip_stream) {
+    if (n == 0) return FDH_SUCCESS;
+    if (!in_off || !out_off || !out_len || !status || !resume) return fail(FDH_ERR_INVALID_ARGUMENT, "null metadata pointer");
+    if (n > 0x7FFFFFFFull) return fail(FDH_ERR_INVALID_ARGUMENT, "too many streams in one call (max 2^31-1)");
+    if (!have_device()) return fail(FDH_ERR_NO_DEVICE, "no HIP device: fdeflate_hip has no CPU fallback");
+    int rc = ensure_canon_tables(static_cast<hipStream_t>(hip_stream));
+    if (rc != FDH_SUCCESS) return rc;
+    rc = fdh_launch_inflate(in, in_off, out, out_off, out_len, status, adler, n, flags, resume, static_cast<hipStream_t>(hip_stream));
     if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "inflate kernel launch");
     return FDH_SUCCESS;
 }

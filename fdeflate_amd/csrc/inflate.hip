@@ -88,6 +88,8 @@ struct InflateBatchArgs {
     uint4* resume;         // nullable: per stream, where a kernel left it: {bit of the block header (0: nowhere), bit to go on
                            // from, output bytes decoded, their Adler-32} -- a ResumePoint.  Only ever read for a stream
                            // whose status says it was written (kPendingResume, kPendingSerial): no initialisation
+    uint4* resume_out;     // nullable (fdh_inflate_batch_resumable): per stream, where a stream that ended InsufficientInput
+                           // or OutputTooLarge can be taken up again (all zero: from its first byte); same layout
 };
 // The resume point a kernel in front left for stream `sid`, whose status is `st` (if any).
 __device__ __forceinline__ ResumePoint resume_point(const InflateBatchArgs& a, const uint64_t sid, const uint32_t st) {
@@ -197,13 +199,34 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
             if (inf.ck.valid) rp = inf.ck;
         }
     }
+    bool retracted = false;
     if (!tiles) {
+        inf.keep_ck = a.resume_out != nullptr;  // (block headers, the last steps in front of the slot's end)
         inf.init(s);
         bool whole = true;
         if (rp.valid) {
             r = inf.run_from<false>(rp);
             whole = r.status == RC_REDO;  // the stream ended before the tail fell in step with the reference's table steps
             if (whole) inf.init(s);
+            retracted = !whole && r.out_len < rp.opos;  // (the first literal of a pair whose second one is cut off)
+        }
+        if (whole && (a.flags & 0x8000u) && a.resume_out && a.resume_out != a.resume) {
+            // ... then from the point this CALL took the stream up at, if that one knows its place among the steps
+            // (the caller's record is still there: a final result overwrites it, and there is none yet)
+            const uint4 v = a.resume_out[sid];
+            ResumePoint first;
+            first.hdr_bit = v.x & 0x3FFFFFFFu;
+            first.step = v.x >> 30;
+            first.bit = v.y;
+            first.opos = v.z;
+            first.adler = v.w;
+            first.valid = v.x != 0 ? 1u : 0u;
+            if (first.valid && first.step != STEP_UNKNOWN) {
+                rp = first;
+                r = inf.run_from<false>(rp);
+                whole = false;
+                retracted = r.out_len < rp.opos;
+            }
         }
         if (whole) r = inf.run<false, false>();
     }
@@ -211,6 +234,12 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
         a.status[sid] = r.status;
         a.out_len[sid] = r.out_len;
         if (a.adler) a.adler[sid] = r.adler;
+        if (a.resume_out) {
+            ResumePoint out = inf.stopped_at(r);
+            if (!out.valid || retracted) out = rp;  // (the point this run started from: still in front of everything missing)
+            const bool again = r.status == ST_INSUFFICIENT_INPUT || r.status == ST_OUTPUT_TOO_LARGE;
+            a.resume_out[sid] = again ? resume_record(out) : make_uint4(0, 0, 0, 0);
+        }
     }
 }
 __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs a) {
@@ -259,7 +288,7 @@ __device__ __forceinline__ void general_fast_one(const InflateBatchArgs& a, Gene
     }
     const StreamArgs s = stream_args(a, sid);
     InflaterT<kFastLitBits, false> inf(lds.tables, lds.io, reinterpret_cast<HeaderScratch*>(lds.io.mlist), lane);
-    inf.keep_ck = a.resume != nullptr && !(a.flags & 0x4000u);  // (what it cannot classify goes on from its last check point)
+    inf.keep_ck = (a.resume != nullptr || a.resume_out != nullptr) && !(a.flags & 0x4000u);  // (what it cannot classify goes on from its last check point)
     inf.init(s);
     const ResumePoint rec = resume_point(a, sid, st);
     const StreamResult r = rec.valid ? inf.run_from<true>(rec) : inf.run<true, false>();
@@ -270,6 +299,10 @@ __device__ __forceinline__ void general_fast_one(const InflateBatchArgs& a, Gene
         a.status[sid] = r.status;
         a.out_len[sid] = r.out_len;
         if (a.adler) a.adler[sid] = r.adler;
+        if (a.resume_out) {
+            const bool again = r.status == ST_INSUFFICIENT_INPUT || r.status == ST_OUTPUT_TOO_LARGE;
+            a.resume_out[sid] = again ? resume_record(inf.ck.valid ? inf.ck : rec) : make_uint4(0, 0, 0, 0);
+        }
     }
 }
 __global__ __launch_bounds__(kWave, FDH_FAST_WAVES_PER_SIMD) void inflate_general_fast_kernel(InflateBatchArgs a) {
@@ -293,12 +326,17 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     const int lane = threadIdx.x;
     rec = make_uint4(0, 0, 0, 0);  // (header bit 0: no resume point)
     if (sid >= a.n) return false;
+    uint32_t st = kPending;
     if (a.only_pending) {  // finished by a kernel in front: nothing to do; left for the exact serial decoder: not ours
-        const uint32_t st = a.status[sid];
-        if (st != kPending) return st != kPendingSerial;
+        st = a.status[sid];
+        if (st != kPending && st != kPendingResume) return st != kPendingSerial;
     }
     const StreamArgs s = stream_args(a, sid);
     if (s.in_len < 8 || s.in_len >= (1ull << 27) || s.cap >= (1u << 30) || s.cap < 16) return false;  // 32-bit bit positions; far sources are read 16 bytes at a time
+    // a stream that was stopped earlier (fdh_inflate_batch_resumable) goes on at its resume point: the block header is
+    // parsed again for the tables, the ring gets the history from the slot
+    const ResumePoint from = resume_point(a, sid, st);
+    if (st == kPendingResume && !from.valid) return false;
     const uint32_t in_bits = (uint32_t)s.in_len * 8;
     // (the wave-serial reader is used for its bit window only: zlib header, block type, trailer)
     InflaterT<kLitBits, false> inf(*reinterpret_cast<TableSetT<kLitBits>*>(&L), *reinterpret_cast<WaveIo*>(&L.u.hdr), nullptr, lane);
@@ -323,10 +361,34 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     o.adler_b = 0;
     uint32_t bitpos = 16, hdr_bit = 16;
     bool fixed_built = false;
+    uint32_t start_bit = 0;  // (a resume point in the middle of a block: where its data goes on)
+    if (from.valid) {
+        if (from.opos > s.cap) return false;
+        o.O = from.opos;
+        o.flushed = from.opos;
+        o.adler_a = from.adler & 0xFFFF;
+        o.adler_b = from.adler >> 16;
+        o.o_ri = (from.opos + inf.gmis) % kLzRing;
+        const uint32_t lo_p = from.opos > kLzRing ? from.opos - kLzRing : 0;
+        const uint8_t* const g = inf.out_al + inf.gmis;
+        for (uint32_t p = lo_p + (uint32_t)lane; p < from.opos; p += kWave)
+            L.ring[(p + inf.gmis) % kLzRing] = __hip_atomic_load(g + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wave_sync();
+        bitpos = (uint32_t)from.hdr_bit;
+        if (from.bit != from.hdr_bit) start_bit = (uint32_t)from.bit;
+        inf.left = in_bits - bitpos;
+        inf.loaded = 0x7FFFFFF0u;
+        inf.seek(bitpos);
+    }
+    const uint32_t O_in = o.O;
     // This kernel gives up on the stream at stream bit `bit` of the block whose header starts at hdr_bit (bit ==
     // hdr_bit: at the header itself): everything in front of it is decoded, so it all goes to the slot with its
     // checksum and the kernels behind take the stream up there instead of at its first byte.
     auto leave = [&](const uint32_t bit) __attribute__((always_inline)) -> bool {
+        if (from.valid && o.O == O_in) {  // nothing gained: the point this call started from stands (it may know more: its step state)
+            rec = resume_record(from);
+            return false;
+        }
         if (o.O != 0 && !(a.flags & 0x4000u)) {
             lz_flush(L, o, true, lane);
             rec = make_uint4(hdr_bit, bit, o.O, (o.adler_b << 16) | o.adler_a);
@@ -372,6 +434,10 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
         }
         const bool last = inf.last_block;
         bitpos = (uint32_t)inf.consumed_bits();
+        if (start_bit != 0) {
+            bitpos = start_bit;
+            start_bit = 0;
+        }
         const LzBounds bd = lz_load_bounds(L.tables);
         LZT(o, 0);
         if (rc == RC_OK) {
@@ -504,7 +570,7 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
     inf.eof_mask = lds.tables.eof[1];
     inf.eof_bits = lds.tables.eof[2];
     inf.hdr_bit = 16;  // (the block header of the prefix, for the check points)
-    inf.keep_ck = a.resume != nullptr && !(a.flags & 0x4000u);
+    inf.keep_ck = (a.resume != nullptr || a.resume_out != nullptr) && !(a.flags & 0x4000u);
     StreamResult r = inf.run<true, true>();
     if (lane == 0) {
         if (needs_serial_recheck(r, a.flags)) {
@@ -514,6 +580,10 @@ __global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(Infla
             a.status[sid] = r.status;
             a.out_len[sid] = r.out_len;
             if (a.adler) a.adler[sid] = r.adler;
+            if (a.resume_out) {
+                const bool again = r.status == ST_INSUFFICIENT_INPUT || r.status == ST_OUTPUT_TOO_LARGE;
+                a.resume_out[sid] = again ? resume_record(inf.ck) : make_uint4(0, 0, 0, 0);
+            }
         }
     }
 }
@@ -863,11 +933,63 @@ extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status)
     return (int)e;
 }
 
+// Statuses of a batch whose streams are taken up at resume points: PENDING_RESUME where there is one, PENDING elsewhere.
+// (... a copy of the records for the kernels to pass on between them, and the list of all streams for the first one)
+__global__ __launch_bounds__(256) void resume_prepare_kernel(uint32_t* status, const uint4* resume, uint4* work, uint32_t* scratch, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const uint4 r = resume[i];
+        work[i] = r;
+        status[i] = r.x != 0 ? fdh::kPendingResume : fdh::kPending;
+        scratch[8 + i] = (uint32_t)i;
+    }
+    if (i == 0) {
+        scratch[2] = 0;            // hand-out counter of the LZ-window kernel
+        scratch[4] = (uint32_t)n;  // the list's count
+        scratch[5] = scratch[6] = scratch[7] = 0;
+    }
+}
+
+// `resume_io` (nullable, n records of 16 bytes): where a stream that ends InsufficientInput / OutputTooLarge can be
+// taken up again; with FDH_FLAG_RESUME_IN (0x8000) also where each stream is to be taken up NOW (all zero: at its
+// first byte) -- the slot then holds the output up to that point, and only the two general kernels run.
 extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
-                                  hipStream_t stream) {
+                                  void* resume_io, hipStream_t stream) {
     if (n == 0) return 0;
-    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            static_cast<uint4*>(resume_io)};
+    if (resume_io && (flags & 0x8000u)) {
+        // The LZ-window kernel takes every stream as far as it can (from its resume point), the 12-bit kernel does the
+        // rest: its tiles know where the reference's table steps start, so the serial decoder can take over at its
+        // check points whatever the data -- the small-table kernel's cannot.  Scratch: a list of all streams for the
+        // persistent wavefronts of the first kernel, its items, and the records the two kernels pass between them
+        // (the caller's array keeps what came in until the final result of a stream overwrites it).
+        int ordinal = 0, cus = 256;
+        if (hipGetDevice(&ordinal) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ordinal) == hipSuccess && v > 0) cus = v;
+        }
+        const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);
+        const size_t list_words = ((size_t)n + 8 + 3) & ~(size_t)3;
+        const size_t lzck_bytes = (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
+        uint32_t* scratch = nullptr;
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), list_words * sizeof(uint32_t) + lzck_bytes + (size_t)n * sizeof(uint4), stream);
+        if (e != hipSuccess) return (int)e;
+        a.lz_counter = scratch + 2;
+        a.list = scratch + 4;   // [0] = count, [4..] = ids (its hand-out words [2], [3] are not used by this kernel)
+        a.lz_ck = reinterpret_cast<uint2*>(scratch + list_words);
+        a.resume = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(a.lz_ck) + lzck_bytes);
+        a.only_pending = 1;
+        hipLaunchKernelGGL(resume_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, status, a.resume_out, a.resume,
+                           scratch, n);
+        if (!(flags & 0x1000u)) hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, stream, a);
+        a.list = nullptr;
+        hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)n), dim3(fdh::kWave), 0, stream, a);
+        e = hipGetLastError();
+        (void)hipFreeAsync(scratch, stream);
+        return (int)e;
+    }
     if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
         int ordinal = 0;
         if (hipGetDevice(&ordinal) == hipSuccess && ordinal >= 0 && ordinal < 64) {

@@ -208,6 +208,8 @@ struct InflaterT {
     ResumePoint ck;          // the last check point
     uint32_t step_state;     // STEP_*: the current position in the reference's chain of table steps (kept while keep_ck)
     bool last_was_pair;      // serial_token: the table entry it took was a pair of literals
+    uint64_t tok_bit;        // where the last serial token started
+    bool stuck_at_step;      // the run ended because serial_token, called at the start of a step, could not go on
 #ifdef FDH_DEBUG_TILES
     unsigned long long gacc[24] = {};
 #endif
@@ -419,6 +421,8 @@ struct InflaterT {
         ck.valid = 0;
         step_state = STEP_UNKNOWN;
         last_was_pair = false;
+        tok_bit = 0;
+        stuck_at_step = false;
         seek(0);
     }
 
@@ -1712,7 +1716,13 @@ struct InflaterT {
             const uint64_t c0 = consumed_bits();
 #endif
             last_was_pair = false;
+            tok_bit = consumed_bits();
+            // (close to the end of the slot every step may be the last one that fits: the place to take the stream
+            //  up again with a larger slot is a check point in front of it)
+            if (keep_ck && step_state == STEP_START && cap - opos <= 320u) take_ck();
+            const bool at_step = step_state == STEP_START;
             uint32_t rc = serial_token();
+            stuck_at_step = rc == RC_STUCK && at_step && opos != cap;
             // (from the start of a step it took a step; from anywhere else a symbol that pairs with nothing puts it in step)
             if (step_state != STEP_START) step_state = last_was_pair ? (uint32_t)STEP_UNKNOWN : (uint32_t)STEP_START;
 #ifdef FDH_DEBUG_TILES
@@ -1762,6 +1772,22 @@ struct InflaterT {
         r.out_len = opos;
         r.adler = adler;
         return r;
+    }
+
+    // Where a stream that ran out of input (r from finish()) can be taken up again once more input has arrived:
+    // the start of the token that did not fit -- the state of the reference's own decoder at that moment -- or,
+    // when it was not a token of block data that stopped the run, the last check point.
+    __device__ __forceinline__ ResumePoint stopped_at(const StreamResult& r) const {
+        ResumePoint rp = ck;
+        if (stuck_at_step && r.status == ST_INSUFFICIENT_INPUT) {
+            rp.hdr_bit = hdr_bit;
+            rp.bit = tok_bit;
+            rp.opos = r.out_len;
+            rp.adler = r.adler;
+            rp.valid = 1;
+            rp.step = STEP_START;
+        }
+        return rp;
     }
 
     // Whole stream.  START_IN_BLOCK: the zlib header and the (final, dynamic) block header were

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -100,6 +101,11 @@ struct fdh_decompressor {
     uint64_t attempts = 0;    // decode attempts so far (introspection)
     size_t ahead_bad_cap = 0; // an attempt that decoded ahead into a slot this large met a hard error (0: none):
     size_t ahead_bad_in = 0;  // ... with this much input buffered; later slots stay below it until more input arrives
+    // Where the last attempt that ran out of input or room stopped (fdh_inflate_batch_resumable): the next attempt
+    // goes on from there -- the bytes in front of it stay in the device slot -- instead of at the first byte.
+    fdh_resume_point resume = {0, 0, 0, 0};
+    uint64_t decoded = 0;     // output bytes decoded by all attempts together (introspection: N for a stream of N bytes
+                              // that is never decoded twice)
 };
 
 extern "C" {
@@ -119,6 +125,8 @@ void fdh_decompressor_ignore_adler32(fdh_decompressor* d) {
 int fdh_decompressor_is_done(const fdh_decompressor* d) { return d && d->done ? 1 : 0; }
 
 uint64_t fdh_decompressor_attempts(const fdh_decompressor* d) { return d ? d->attempts : 0; }
+
+uint64_t fdh_decompressor_decoded_bytes(const fdh_decompressor* d) { return d ? d->decoded : 0; }
 
 int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t input_len, uint8_t* output,
                           size_t output_len, size_t output_position, size_t* consumed, size_t* produced,
@@ -224,27 +232,43 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     HIP_TRY(d->meta.reserve(64, 0));
     // a hipMalloc'd buffer can be empty only before the first byte arrives
     HIP_TRY(d->in.reserve(16, d->in_len));
-    uint32_t host_res[4] = {0, 0, 0, 0};
+    uint32_t host_res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
-        {   // (every attempt decodes from the first byte: nothing to keep)
-            hipError_t re = d->out.reserve(cap + 16, 0);
+        {   // (what lies in front of the resume point, and what has been decoded ahead of the caller, stays)
+            const size_t keep = std::min<size_t>(std::max<size_t>(d->ahead_have, d->resume.out_bytes), d->out.cap);
+            hipError_t re = d->out.reserve(cap + 16, keep);
             if (re == hipErrorOutOfMemory && cap != cap_exact) {  // no room to decode ahead: the exact slot may still fit
                 (void)hipGetLastError();
                 cap = cap_exact;
-                re = d->out.reserve(cap + 16, 0);
+                re = d->out.reserve(cap + 16, keep);
             }
             HIP_TRY(re);
         }
+        // the attempt goes on from where the last one stopped, if that lies inside this slot
+        // (FDH_STREAM_NO_RESUME=1: every attempt from the first byte, as in rounds 1-3 -- for A/B measurements)
+        static const bool no_resume = std::getenv("FDH_STREAM_NO_RESUME") != nullptr;
+        const bool go_on = !no_resume && d->resume.header_bit != 0 && d->resume.out_bytes <= cap;
         uint64_t meta[8] = {0, (uint64_t)d->in_len, 0, (uint64_t)cap, 0, 0, 0, 0};
+        if (go_on) std::memcpy(&meta[6], &d->resume, sizeof(d->resume));
         HIP_TRY(hipMemcpy(d->meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
         uint64_t* m = reinterpret_cast<uint64_t*>(d->meta.p);
         uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
-        int rc = fdh_inflate_batch(d->in.p, m, d->out.p, m + 2, res, res + 1, res + 2, 1,
-                                   d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u, nullptr);
+        int rc = fdh_inflate_batch_resumable(d->in.p, m, d->out.p, m + 2, res, res + 1, res + 2, 1,
+                                             (d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u) | (go_on ? FDH_FLAG_RESUME_IN : 0u),
+                                             reinterpret_cast<fdh_resume_point*>(m + 6), nullptr);
         if (rc != FDH_SUCCESS) return rc;
         HIP_TRY(hipMemcpy(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost));  // synchronises the null stream
         d->attempts++;
         const uint32_t st1 = host_res[1];
+        if (st1 == FDH_STREAM_OK || st1 == FDH_WRONG_CHECKSUM || st1 == FDH_OUTPUT_TOO_LARGE || st1 == FDH_INSUFFICIENT_INPUT) {
+            const size_t from = go_on ? d->resume.out_bytes : 0;
+            if (host_res[0] > from) d->decoded += host_res[0] - from;
+        }
+        if (st1 == FDH_OUTPUT_TOO_LARGE || st1 == FDH_INSUFFICIENT_INPUT) {
+            fdh_resume_point got;
+            std::memcpy(&got, &host_res[4], sizeof(got));
+            if (got.header_bit != 0) d->resume = got;  // (none: the one this attempt started from still stands)
+        }
         const bool classified = st1 == FDH_STREAM_OK || st1 == FDH_WRONG_CHECKSUM || st1 == FDH_OUTPUT_TOO_LARGE ||
                                 st1 == FDH_INSUFFICIENT_INPUT;
         // a hard error somewhere in the part decoded ahead: the caller must not hear of it before its

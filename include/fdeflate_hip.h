@@ -74,6 +74,7 @@ enum {
 #define FDH_FLAG_INTERVALS_ONLY 0x800u /* debug: run only the interval kernel (what it leaves stays PENDING) */
 #define FDH_FLAG_NO_LZ          0x1000u /* tests/A-B: skip the LZ-window kernel (general streams go to the tile decoders) */
 #define FDH_FLAG_LZ_ONLY        0x2000u /* debug: nothing behind the LZ-window kernel runs (what it leaves stays PENDING) */
+#define FDH_FLAG_RESUME_IN      0x8000u /* fdh_inflate_batch_resumable: `resume` also says where to take each stream up */
 #define FDH_FLAG_NO_CHECKPOINTS 0x4000u /* tests/A-B: the exact serial decoder re-derives a doubtful result from the stream's first byte, not from the last check point */
 #define FDH_FLAG_SPANS          0x100u /* experimental: segment-parallel "span" decoder inside the 12-bit general kernel */
 
@@ -102,6 +103,36 @@ enum {
 int fdh_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
                       const uint64_t *out_off, uint32_t *out_len, uint32_t *status,
                       uint32_t *adler, uint64_t n, uint32_t flags, void *hip_stream);
+
+/*
+ * fdh_inflate_batch_resumable -- fdh_inflate_batch that can stop and go on: the device-side counterpart of
+ * the reference's resumable `Decompressor` (State / BitBuffer / QueuedOutput, src/decompress.rs:84-121), for
+ * callers that get a stream's input or its output room in pieces (fdh_decompressor_read is built on it).
+ *
+ *   resume[n]   (device) per stream, 16 bytes.  OUT: for a stream that ended FDH_INSUFFICIENT_INPUT or
+ *               FDH_OUTPUT_TOO_LARGE, a place inside the stream from which decoding can go on later -- a bit
+ *               position at the start of one of the reference's decoding steps, the header of the block it
+ *               lies in, the number of output bytes in front of it and their Adler-32 -- or all zero (go on
+ *               from the first byte).  All zero for every other status.
+ *               IN, with FDH_FLAG_RESUME_IN: where to take each stream up in THIS call (all zero: at its first
+ *               byte).  The stream's input must start with the same bytes as in the call that produced the
+ *               record (more may have arrived behind them), and its output slot must start at the same
+ *               place in the caller's data: it holds the `out_bytes` decoded so far (the LZ77 history) and
+ *               may have grown.  With that flag only the tile / serial decoders run (the segment-parallel
+ *               kernels start at a stream's first byte).
+ * Status, length and Adler-32 of a stream that was stopped and taken up again -- any number of times, at any
+ * split of input and output -- equal those of one fdh_inflate_batch call on the whole of it.
+ */
+typedef struct fdh_resume_point {
+  uint32_t header_bit; /* stream bit of the block header, | step state << 30; 0: no resume point */
+  uint32_t bit;        /* stream bit to go on from */
+  uint32_t out_bytes;  /* output bytes in front of it */
+  uint32_t adler32;    /* their Adler-32 */
+} fdh_resume_point;
+int fdh_inflate_batch_resumable(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
+                                const uint64_t *out_off, uint32_t *out_len, uint32_t *status,
+                                uint32_t *adler, uint64_t n, uint32_t flags,
+                                fdh_resume_point *resume, void *hip_stream);
 
 /*
  * fdh_deflate_ultrafast_batch -- `compress_to_vec_ultra_fast` (src/compress/mod.rs:313-317,
@@ -232,6 +263,10 @@ int fdh_decompressor_is_done(const fdh_decompressor *d);
 /* Introspection: decode attempts made so far (a stream drained through a small window needs O(log) of
  * them: every attempt decodes ahead of what the caller can take, see fdh_decompressor_read). */
 uint64_t fdh_decompressor_attempts(const fdh_decompressor *d);
+/* Introspection: output bytes decoded by all attempts together.  An attempt goes on from where the last one
+ * stopped (fdh_inflate_batch_resumable), so for a stream of N decoded bytes this stays close to N however the
+ * input and the room arrive (rounds 1-3: every attempt started at the first byte). */
+uint64_t fdh_decompressor_decoded_bytes(const fdh_decompressor *d);
 int fdh_decompressor_read(fdh_decompressor *d, const uint8_t *input, size_t input_len,
                           uint8_t *output, size_t output_len, size_t output_position,
                           size_t *consumed, size_t *produced, uint32_t *stream_status);

@@ -14,6 +14,16 @@ pub struct fdh_decompressor {
     _private: [u8; 0],
 }
 
+/// `fdh_resume_point`: where a stream that ran out of input or room can be taken up again.
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct fdh_resume_point {
+    pub header_bit: u32,
+    pub bit: u32,
+    pub out_bytes: u32,
+    pub adler32: u32,
+}
+
 /// `fdh_shard_t`: the device-resident shard of one GPU for `fdh_inflate_batch_multi`.
 #[repr(C)]
 pub struct fdh_shard_t {
@@ -33,6 +43,10 @@ extern "C" {
     pub fn fdh_inflate_batch(input: *const u8, in_off: *const u64, out: *mut u8, out_off: *const u64,
                              out_len: *mut u32, status: *mut u32, adler: *mut u32, n: u64, flags: u32,
                              hip_stream: *mut c_void) -> c_int;
+    /// `fdh_inflate_batch` that can stop and go on (16-byte resume points per stream, see the header).
+    pub fn fdh_inflate_batch_resumable(input: *const u8, in_off: *const u64, out: *mut u8, out_off: *const u64,
+                                       out_len: *mut u32, status: *mut u32, adler: *mut u32, n: u64, flags: u32,
+                                       resume: *mut fdh_resume_point, hip_stream: *mut c_void) -> c_int;
     // compress_to_vec_ultra_fast per buffer (src/compress/mod.rs:313-317)
     pub fn fdh_deflate_ultrafast_batch(input: *const u8, in_off: *const u64, out: *mut u8, out_off: *const u64,
                                        out_len: *mut u32, n: u64, hip_stream: *mut c_void) -> c_int;
@@ -53,6 +67,8 @@ extern "C" {
     pub fn fdh_decompressor_is_done(d: *const fdh_decompressor) -> c_int;
     /// Introspection (not part of the reference API): decode attempts made so far.
     pub fn fdh_decompressor_attempts(d: *const fdh_decompressor) -> u64;
+    /// Introspection (not part of the reference API): output bytes decoded by all attempts together.
+    pub fn fdh_decompressor_decoded_bytes(d: *const fdh_decompressor) -> u64;
     pub fn fdh_decompressor_read(d: *mut fdh_decompressor, input: *const u8, input_len: usize, output: *mut u8,
                                  output_len: usize, output_position: usize, consumed: *mut usize,
                                  produced: *mut usize, stream_status: *mut u32) -> c_int;

@@ -1,0 +1,160 @@
+"""fdh_inflate_batch_resumable: a stream stopped by a short input or a full slot and taken up again at the resume
+point the call left -- any number of times, at any split -- ends with the status, length, Adler-32 and bytes of
+one call on the whole of it (the oracle's one-shot wrapper, reference src/decompress.rs:1111-1144)."""
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fd():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import fdeflate_amd
+    return fdeflate_amd
+
+
+def _streams():
+    from fdeflate_amd import synth
+    rnd = random.Random(9)
+    noisy = synth.gen_stream_np(0, 65536).tobytes()
+    half = synth.gen_stream_np(15, 50000).tobytes()
+    text = (b"a stream fed to the decoder a piece at a time, " * 500) + bytes(rnd.randrange(256) for _ in range(4000))
+    small = bytes((b % 7) for b in noisy[:30000])
+    out = [("uf", ob.compress_ultra_fast(noisy), noisy), ("uf_half", ob.compress_ultra_fast(half), half),
+           ("zlib6", zlib.compress(noisy, 6), noisy), ("zlib9text", zlib.compress(text, 9), text),
+           ("zlib1", zlib.compress(half, 1), half), ("stored", ob.compress_stored(noisy[:40000]), noisy[:40000])]
+    for strat, sname in ((zlib.Z_FIXED, "fixed"), (zlib.Z_HUFFMAN_ONLY, "huff"), (zlib.Z_RLE, "rle")):
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strat)
+        out.append((sname, c.compress(small) + c.flush(), small))
+    c = zlib.compressobj(6)
+    multi = b"".join(c.compress(noisy[k:k + 7000]) + c.flush(zlib.Z_FULL_FLUSH) for k in range(0, 42000, 7000)) + c.flush()
+    out.append(("flushes", multi, noisy[:42000]))
+    bad = bytearray(zlib.compress(text, 6))
+    bad[len(bad) // 2] ^= 0x10
+    out.append(("damaged", bytes(bad), None))
+    bad = bytearray(ob.compress_ultra_fast(half))
+    bad[-2] ^= 1
+    out.append(("trailer", bytes(bad), None))
+    return out
+
+
+def _drive(fd, comps, in_cuts, out_cuts):
+    """All streams side by side in one batch; call k sees input up to in_cuts[i][k] and room up to out_cuts[i][k].
+    A slot is [out_off[j], out_off[j + 1]): the room a stream does not have yet is the slot of an empty stream
+    behind it (2n streams per call, every other one of length zero: InsufficientInput, nothing written).  The
+    input is packed anew for every call -- only the output has to stay where it is."""
+    import torch
+    n = len(comps)
+    cap = [oc[-1] for oc in out_cuts]
+    out_base = np.zeros(n + 1, dtype=np.int64)
+    out_base[1:] = np.cumsum([c + 16 for c in cap])
+    d_out = torch.full((int(out_base[-1]),), 0xA5, dtype=torch.uint8, device="cuda")
+    resume = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    steps = max(max(len(x) for x in in_cuts), max(len(x) for x in out_cuts))
+    res = None
+    for k in range(steps):
+        io = np.zeros(2 * n + 1, dtype=np.int64)
+        oo = np.zeros(2 * n + 1, dtype=np.int64)
+        parts = []
+        pos = 0
+        for i in range(n):
+            cut = in_cuts[i][min(k, len(in_cuts[i]) - 1)]
+            parts.append(comps[i][:cut])
+            io[2 * i] = pos
+            pos += cut
+            io[2 * i + 1] = pos
+            oo[2 * i] = out_base[i]
+            oo[2 * i + 1] = out_base[i] + out_cuts[i][min(k, len(out_cuts[i]) - 1)]
+        io[2 * n] = pos
+        oo[2 * n] = out_base[n]
+        d_in = torch.from_numpy(np.frombuffer(b"".join(parts) + bytes(16), dtype=np.uint8).copy()).cuda()
+        r2 = torch.zeros((2 * n, 4), dtype=torch.int32, device="cuda")
+        r2[0::2] = resume
+        ln, st, ad = fd.inflate_batch_resumable(d_in, torch.from_numpy(io).cuda(), d_out, torch.from_numpy(oo).cuda(), r2,
+                                                resume_in=(k > 0))
+        torch.cuda.synchronize()
+        resume = r2[0::2].contiguous()
+        res = (ln.cpu().numpy().view(np.uint32)[0::2].copy(), st.cpu().numpy().view(np.uint32)[0::2].copy(),
+               ad.cpu().numpy().view(np.uint32)[0::2].copy())
+    h = d_out.cpu().numpy()
+    outs = [h[out_base[i]:out_base[i] + cap[i]] for i in range(n)]
+    guards = all((h[out_base[i] + cap[i]:out_base[i + 1]] == 0xA5).all() for i in range(n))
+    return res, outs, guards, resume.cpu().numpy()
+
+
+def _check_final(names, comps, caps, res, outs):
+    import gpu_harness
+    ln, st, ad = res
+    for i, name in enumerate(names):
+        rs, rl, ra, ro = gpu_harness.oracle_inflate([comps[i]], [caps[i]])
+        es, el, ea, eo = rs[0], rl[0], ra[0], ro[0]
+        assert int(st[i]) == es, (name, int(st[i]), es)
+        if es in (0, 17):
+            assert int(ln[i]) == el and outs[i][:el].tobytes() == eo, (name, int(ln[i]), el)
+        if es == 0:
+            assert int(ad[i]) == ea, name
+
+
+def test_input_in_pieces(fd):
+    """The input arrives in pieces (fixed and random sizes), the slot is large enough from the start."""
+    items = _streams()
+    names = [x[0] for x in items]
+    comps = [x[1] for x in items]
+    caps = [(len(x[2]) if x[2] is not None else 70000) + 64 for x in items]
+    rnd = random.Random(4)
+    for mode in ("thirds", "random", "tiny_tail"):
+        in_cuts = []
+        for c in comps:
+            if mode == "thirds":
+                cuts = [len(c) // 3, (2 * len(c)) // 3, len(c)]
+            elif mode == "random":
+                cuts = sorted(rnd.randrange(1, len(c)) for _ in range(6)) + [len(c)]
+            else:
+                cuts = [len(c) - 9, len(c) - 5, len(c) - 4, len(c) - 1, len(c)]
+            in_cuts.append(cuts)
+        out_cuts = [[cap] for cap in caps]
+        res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts)
+        assert guards
+        _check_final(names, comps, caps, res, outs)
+
+
+def test_output_room_in_pieces(fd):
+    """All of the input is there, the slot grows from call to call (OutputTooLarge in between)."""
+    items = [x for x in _streams() if x[2] is not None]
+    names = [x[0] for x in items]
+    comps = [x[1] for x in items]
+    rnd = random.Random(5)
+    for final_slack in (0, 10):
+        caps = [len(x[2]) + final_slack for x in items]
+        in_cuts = [[len(c)] for c in comps]
+        out_cuts = [sorted(rnd.randrange(1, cap) for _ in range(5)) + [cap] for cap in caps]
+        res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts)
+        assert guards
+        _check_final(names, comps, caps, res, outs)
+
+
+def test_both_in_pieces_and_the_work_done(fd):
+    """Input and room grow together; a resume point moves forward with them: the later calls start where the
+    earlier ones stopped, not at the first byte."""
+    items = [x for x in _streams() if x[2] is not None]
+    names = [x[0] for x in items]
+    comps = [x[1] for x in items]
+    caps = [len(x[2]) for x in items]
+    steps = 8
+    in_cuts = [[max(1, (len(c) * (k + 1)) // steps) for k in range(steps)] for c in comps]
+    out_cuts = [[max(1, (cap * (k + 2)) // steps) if k + 2 < steps else cap for k in range(steps)] for cap in caps]
+    res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts)
+    assert guards
+    _check_final(names, comps, caps, res, outs)
+    # the resume points after half of the steps lie well inside the streams
+    res, outs, guards, rec = _drive(fd, comps, [x[:steps // 2] for x in in_cuts], [x[:steps // 2] for x in out_cuts])
+    inside = [i for i in range(len(items)) if rec[i][0] != 0 and int(rec[i][1]) > 8 * len(comps[i]) // 4]
+    assert len(inside) >= len(items) - 2, (len(inside), [(names[i], rec[i].tolist()) for i in range(len(items))])

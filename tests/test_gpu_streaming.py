@@ -308,6 +308,51 @@ def test_bounded_output_with_history_compaction(fd):
     assert bytes(got) == raw
 
 
+def test_attempts_go_on_where_the_last_one_stopped(fd):
+    """The device-side resume points (fdh_inflate_batch_resumable): however the input arrives and however small
+    the window, the attempts of one stream together decode little more than the stream once (rounds 1-3: every
+    attempt started at the first byte -- 2 x with decode-ahead, O(N^2 / chunk) for input in small pieces).  Input
+    in 20 KB pieces into a large buffer; everything at once through a 16 KiB window; both at once; for a zlib
+    level-6 stream of many blocks and for a 1.5 MB stream in the ultra-fast format (one block, pairs of literals)."""
+    r = np.random.default_rng(5)
+    raw = bytes((np.cumsum(r.integers(-3, 4, size=1_500_000)) & 0xFF).astype(np.uint8))
+    for comp in (zlib.compress(raw, 6), ob.compress_ultra_fast(raw)):
+        # input in pieces, room for everything
+        d = fd.Decompressor()
+        buf = bytearray(len(raw) + 64)
+        pos = 0
+        for k in range(0, len(comp), 20_000):
+            c, p = d.read(comp[k:k + 20_000], buf, pos)
+            pos += p
+        while not d.is_done():
+            c, p = d.read(b"", buf, pos)
+            pos += p
+            assert p > 0 or d.is_done()
+        assert bytes(buf[:pos]) == raw
+        assert d.decoded_bytes() <= len(raw) * 1.05 + 70_000, (d.decoded_bytes(), len(raw), d.attempts())
+        # everything at once through a small window, and both in pieces
+        for piece in (len(comp), 50_000):
+            d = fd.Decompressor()
+            got = bytearray()
+            buf = bytearray(32_768 + 16_384)
+            pos = 0
+            k = 0
+            calls = 0
+            while not d.is_done():
+                calls += 1
+                assert calls < 20_000
+                chunk = comp[k:k + piece]
+                c, p = d.read(chunk, buf, pos)
+                k += c
+                got += buf[pos:pos + p]
+                pos += p
+                if pos > 32_768:
+                    buf[:32_768] = buf[pos - 32_768:pos]
+                    pos = 32_768
+            assert bytes(got) == raw
+            assert d.decoded_bytes() <= len(raw) * 1.05 + 70_000, (piece, d.decoded_bytes(), len(raw), d.attempts())
+
+
 def test_large_stream_through_a_small_window_decodes_ahead(fd):
     """A 3 MB multi-block stream with the whole input at hand, drained through a 16 KiB window (the
     png-crate pattern with history compaction): bytes and end state as the oracle's, and the number
