@@ -335,7 +335,12 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     if (s.in_len < 8 || s.in_len >= (1ull << 27) || s.cap >= (1u << 30) || s.cap < 16) return false;  // 32-bit bit positions; far sources are read 16 bytes at a time
     // a stream that was stopped earlier (fdh_inflate_batch_resumable) goes on at its resume point: the block header is
     // parsed again for the tables, the ring gets the history from the slot
+#ifdef FDH_LZ_NO_RESUME_IN
+    ResumePoint from;
+    from.valid = 0; from.step = 0; from.hdr_bit = 0; from.bit = 0; from.opos = 0; from.adler = 0;
+#else
     const ResumePoint from = resume_point(a, sid, st);
+#endif
     if (st == kPendingResume && !from.valid) return false;
     const uint32_t in_bits = (uint32_t)s.in_len * 8;
     // (the wave-serial reader is used for its bit window only: zlib header, block type, trailer)

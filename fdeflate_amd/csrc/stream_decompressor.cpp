@@ -14,15 +14,18 @@
 //     bytes"; InsufficientInput -> the engine reports how many bytes the reference had produced when
 //     it ran dry, and exactly those are delivered;
 //   * only output[output_position ..] is written, never more than the room, and the bytes in
-//     front of output_position are not needed (each attempt decodes from the start of the stream,
-//     the LZ77 history lives in the device slot).
+//     front of output_position are not needed (the LZ77 history lives in the device slot);
+//   * an attempt goes on where the last one stopped: fdh_inflate_batch_resumable hands back a resume
+//     point (bit position at the start of one of the reference's decoding steps, block header, output
+//     bytes, Adler-32) for a stream that ran out of input or room, and takes the stream up there in the
+//     next call -- the counterpart of the reference's State / BitBuffer / QueuedOutput, kept on the device.
 //
 // Draining through a small output window: an attempt decodes AHEAD of what the caller can take (slot =
 // twice what has been delivered + 64 KiB) and the following calls are served from that prefix, so a
 // stream of N bytes costs O(N) decoded bytes however small the window (round 2: O(N^2 / window)).  A
 // hard error in the part decoded ahead is not reported early: the attempt is repeated with the exact
 // slot, whose classification is the reference's.
-// Re-decoding the prefix on every call would be quadratic for a large stream fed in small pieces;
+// An attempt costs a few kernel launches and a round trip to the device whatever it decodes;
 // above kAlwaysBelow buffered bytes an attempt is made only once the stream has grown by 1/8 --
 // or when the caller passes an empty `input`, which is how both the reference's test harness
 // (src/decompress/tests/test_utils.rs:70-74: chunk size 0 once the input is exhausted) and the png
