@@ -1,7 +1,8 @@
 """Randomised parity soak on the GPU box (not collected by pytest):
     python tests/soak_gpu.py <first seed> <end seed>
 General encoder (level 1 / RLE) and the PNG kernels against the oracle on random shapes and
-contents, with guard bytes; several images per wavefront for the PNG pipeline."""
+contents, with guard bytes; several images per wavefront for the PNG pipeline; zlib / ultra-fast streams whole,
+cut and damaged; cut streams' partial lengths; the resumable batch (FDH_SOAK_ONLY=resume: the last two only)."""
 import os, sys, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -207,10 +208,85 @@ def order_round(seed):
         assert int(adh[i]) == int.from_bytes(t.tobytes(), "big"), (seed, i)
 
 
+def _rand_buffer(r, n):
+    kind = int(r.integers(0, 6))
+    if kind == 0: return r.integers(0, 256, n, dtype=np.uint8)
+    if kind == 1: return r.integers(0, int(r.integers(1, 8)), n, dtype=np.uint8)
+    if kind == 2: return np.tile(r.integers(0, 256, max(1, n // 40), dtype=np.uint8), 50)[:n]
+    if kind == 3:
+        a = r.integers(0, 256, n, dtype=np.uint8); a[r.random(n) < 0.8] = 0; return a
+    if kind == 4: return (r.integers(-3, 4, n) & 0xFF).astype(np.uint8)     # small residuals: short codes, pairs of literals
+    return (np.cumsum(r.integers(-2, 3, n)) & 0xFF).astype(np.uint8)
+
+
+def _rand_stream(r, n):
+    a = _rand_buffer(r, n).tobytes()
+    if int(r.integers(0, 3)) == 0:
+        return ob.compress_ultra_fast(a), a
+    co = zlib.compressobj(int(r.integers(0, 10)), zlib.DEFLATED, 15, int(r.integers(1, 10)), int(r.choice([0, 1, 2, 3, 4])))
+    return co.compress(a) + co.flush(), a
+
+
+def cut_round(seed):
+    """Streams of both formats cut at random places: InsufficientInput with the length and the bytes the
+    oracle's streaming decoder had produced from that prefix (what the check points / the step tracking of the
+    tile decoders are for), with and without check points."""
+    import gpu_harness
+    r = np.random.default_rng(seed)
+    blobs, exp = [], []
+    for k in range(48):
+        c, a = _rand_stream(r, int(r.integers(200, 90000)))
+        for cut in sorted(set(int(x) for x in r.integers(3, max(4, len(c)), 6))):
+            d = ob.Decompressor()
+            out = np.zeros(len(a) + 64, dtype=np.uint8)
+            st, cons, p = d.read(c[:cut], out, 0)
+            if st == 0 and not d.is_done():
+                blobs.append(c[:cut]); exp.append(out[:p].tobytes())
+    caps = [len(e) + 300 for e in exp]
+    for flags in (0, 0x4000, 0x1000):
+        st, ln, ad, outs, ok = gpu_harness.gpu_inflate(blobs, caps, flags)
+        assert ok, (seed, "guard")
+        for i, e in enumerate(exp):
+            assert int(st[i]) == 2 and int(ln[i]) == len(e) and outs[i][:len(e)].tobytes() == e, (seed, flags, i, int(st[i]), int(ln[i]), len(e))
+
+
+def resume_round(seed):
+    """fdh_inflate_batch_resumable: random streams, the input and the slot growing in random steps, some of them
+    damaged: the last call's status, length, checksum and bytes are those of one call on the whole stream."""
+    import test_gpu_resume as tr
+    import gpu_harness
+    r = np.random.default_rng(seed)
+    comps, caps = [], []
+    for k in range(24):
+        c, a = _rand_stream(r, int(r.integers(1, 120000)))
+        mut = int(r.integers(0, 8))
+        if mut == 1 and len(c) > 8:
+            b = bytearray(c); b[int(r.integers(2, len(c)))] ^= 1 << int(r.integers(0, 8)); c = bytes(b)
+        if mut == 2 and len(c) > 8: c = c[:int(r.integers(2, len(c)))]
+        comps.append(c)
+        caps.append(max(1, len(a) + int(r.choice([0, 0, 50, -int(r.integers(1, 40))]))))
+    steps = int(r.integers(2, 7))
+    in_cuts = [sorted(int(x) for x in r.integers(1, len(c) + 1, steps - 1)) + [len(c)] for c in comps]
+    out_cuts = [sorted(int(x) for x in r.integers(1, cap + 1, steps - 1)) + [cap] for cap in caps]
+    (ln, st, ad), outs, guards, _ = tr._drive(fd, comps, in_cuts, out_cuts)
+    assert guards, (seed, "guard")
+    for i, c in enumerate(comps):
+        est, eout, ead = ob.decompress_bounded(c, caps[i])
+        assert int(st[i]) == est, (seed, i, int(st[i]), est)
+        if est in (0, 17):
+            assert int(ln[i]) == len(eout) and outs[i][:len(eout)].tobytes() == eout, (seed, i, int(ln[i]), len(eout))
+        if est == 0:
+            assert int(ad[i]) == ead, (seed, i)
+
+
 ONLY = os.environ.get("FDH_SOAK_ONLY", "")
 for s in range(int(sys.argv[1]), int(sys.argv[2])):
+    if ONLY == "resume":
+        cut_round(6000 + s); resume_round(7000 + s)
+        print("seed", s, "ok", flush=True)
+        continue
     if ONLY not in ("uf", "order"):
-        enc_round(1000 + s); png_round(2000 + s); dec_round(3000 + s)
+        enc_round(1000 + s); png_round(2000 + s); dec_round(3000 + s); cut_round(6000 + s); resume_round(7000 + s)
     if ONLY != "order":
         uf_round(4000 + s)
     if s % 8 == 0 or ONLY == "order":
