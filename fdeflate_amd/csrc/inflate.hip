@@ -386,20 +386,16 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
         inf.seek(bitpos);
     }
     const uint32_t O_in = o.O;
-    // This kernel gives up on the stream at stream bit `bit` of the block whose header starts at hdr_bit (bit ==
-    // hdr_bit: at the header itself): everything in front of it is decoded, so it all goes to the slot with its
-    // checksum and the kernels behind take the stream up there instead of at its first byte.
-    auto leave = [&](const uint32_t bit) __attribute__((always_inline)) -> bool {
-        if (from.valid && o.O == O_in) {  // nothing gained: the point this call started from stands (it may know more: its step state)
-            rec = resume_record(from);
-            return false;
-        }
-        if (o.O != 0 && !(a.flags & 0x4000u)) {
-            lz_flush(L, o, true, lane);
-            rec = make_uint4(hdr_bit, bit, o.O, (o.adler_b << 16) | o.adler_a);
-        }
-        return false;
-    };
+    // This kernel gives up on the stream at stream bit `leave_bit` of the block whose header starts at hdr_bit
+    // (leave_bit == hdr_bit: at the header itself): everything in front of it is decoded, so it all goes to the slot
+    // with its checksum and the kernels behind take the stream up there instead of at its first byte.  (ONE place
+    // does that, at the end: a dozen inlined copies of the flush cost the kernel 2 % of its speed.)
+    uint32_t leave_bit = 0;
+#define LZ_LEAVE(bit_)        \
+    do {                      \
+        leave_bit = (bit_);   \
+        goto lz_leave;        \
+    } while (0)
 #ifdef FDH_LZ_DEBUG
     o.tq = clock64();
 #endif
@@ -407,20 +403,20 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     for (;;) {  // blocks
         hdr_bit = bitpos;
         inf.refill();
-        if (inf.left < 10) return leave(hdr_bit);
+        if (inf.left < 10) LZ_LEAVE(hdr_bit);
         const uint32_t type = ((uint32_t)inf.bb >> 1) & 3;
-        if (type == 0 || type == 3) return leave(hdr_bit);  // stored blocks: the kernels behind
+        if (type == 0 || type == 3) LZ_LEAVE(hdr_bit);  // stored blocks: the kernels behind
         uint32_t rc = RC_OK;
         inf.last_block = ((uint32_t)inf.bb & 1) != 0;
         if (type == 2) {  // dynamic: this kernel's own parser and table builder
-            if (inf.left < 17) return leave(hdr_bit);
+            if (inf.left < 17) LZ_LEAVE(hdr_bit);
             const uint32_t hlit = (((uint32_t)inf.bb >> 3) & 31) + 257, hdist = (((uint32_t)inf.bb >> 8) & 31) + 1;
             const uint32_t hclen = (((uint32_t)inf.bb >> 13) & 15) + 4;
-            if (hlit > 286 || hdist > 30) return leave(hdr_bit);
+            if (hlit > 286 || hdist > 30) LZ_LEAVE(hdr_bit);
             inf.consume(17);
             fixed_built = false;
             LZT(o, 0);
-            if (!lz_parse_dynamic(L, inf, hlit, hdist, hclen, lane, o)) return leave(hdr_bit);
+            if (!lz_parse_dynamic(L, inf, hlit, hdist, hclen, lane, o)) LZ_LEAVE(hdr_bit);
             lz_build_sub(L, lane);
             LZT(o, 17);
         } else {  // fixed: the same builder on the lengths of src/tables.rs:207-232 (an empty block is one end-of-block token)
@@ -432,7 +428,7 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
                     const uint32_t sy = (uint32_t)lane + 64u * k;
                     ll[k] = sy < 144 ? 8u : sy < 256 ? 9u : sy < 280 ? 7u : sy < 288 ? 8u : 0u;
                 }
-                if (!lz_build_tables(L, ll, lane < 32 ? 5u : 0u, lane, o)) return leave(hdr_bit);
+                if (!lz_build_tables(L, ll, lane < 32 ? 5u : 0u, lane, o)) LZ_LEAVE(hdr_bit);
                 lz_build_sub(L, lane);
                 fixed_built = true;
             }
@@ -448,12 +444,12 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
         if (rc == RC_OK) {
             uint32_t qcap = kLzRange;
             for (uint32_t nspans = 0;; nspans++) {  // super-spans
-                if (bitpos >= in_bits || nspans > in_bits) return leave(bitpos);
+                if (bitpos >= in_bits || nspans > in_bits) LZ_LEAVE(bitpos);
                 const uint32_t res = lz_superspan(L, o, bd, lin, bitpos, eob_bits, qcap, lane);
                 if (res == LZ_DISTRUST) return false;
-                if (res == LZ_BAIL) return leave(bitpos);
+                if (res == LZ_BAIL) LZ_LEAVE(bitpos);
                 if (res == LZ_SHRINK) {  // an item that does not fit an image: shorter phases from there on
-                    if (qcap <= 8) return leave(bitpos);
+                    if (qcap <= 8) LZ_LEAVE(bitpos);
                     qcap = max(8u, qcap / 4);
                     continue;
                 }
@@ -461,32 +457,43 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
             }
         }
         // back to the wave-serial reader (its window shares LDS with the span's stage: reload)
-        if (bitpos > in_bits) return leave(bitpos - eob_bits);
+        if (bitpos > in_bits) LZ_LEAVE(bitpos - eob_bits);
         inf.left = in_bits - bitpos;
         inf.loaded = 0x7FFFFFF0u;
         inf.seek(bitpos);
         if (last) break;
     }
     // (a trailer that is cut short or wrong: the exact kernels take the stream up at the last end-of-block code)
-    uint32_t stored = 0;
-    if (inf.read_trailer(stored) != RC_OK) return leave(bitpos - eob_bits);
-    lz_flush(L, o, true, lane);
-    const uint32_t adler = (o.adler_b << 16) | o.adler_a;
-    if (!(a.flags & 1u) && stored != adler) return leave(bitpos - eob_bits);  // WrongChecksum is the exact kernels' verdict
-    if (lane == 0) {
-        a.status[sid] = ST_OK;
-        a.out_len[sid] = o.O;
-        if (a.adler) a.adler[sid] = adler;
-    }
-    LZT(o, 8);
+    {
+        uint32_t stored = 0;
+        if (inf.read_trailer(stored) != RC_OK) LZ_LEAVE(bitpos - eob_bits);
+        lz_flush(L, o, true, lane);
+        const uint32_t adler = (o.adler_b << 16) | o.adler_a;
+        if (!(a.flags & 1u) && stored != adler) LZ_LEAVE(bitpos - eob_bits);  // WrongChecksum is the exact kernels' verdict
+        if (lane == 0) {
+            a.status[sid] = ST_OK;
+            a.out_len[sid] = o.O;
+            if (a.adler) a.adler[sid] = adler;
+        }
+        LZT(o, 8);
 #ifdef FDH_LZ_DEBUG
-    if (lane == 0) {
-        for (int k = 0; k < 32; k++)
-            if (o.t[k]) atomicAdd(&g_lzstat[k], o.t[k]);
-        atomicAdd(&g_lzstat[31], 1ull);
-    }
+        if (lane == 0) {
+            for (int k = 0; k < 32; k++)
+                if (o.t[k]) atomicAdd(&g_lzstat[k], o.t[k]);
+            atomicAdd(&g_lzstat[31], 1ull);
+        }
 #endif
+    }
     return true;
+lz_leave:
+    if (from.valid && o.O == O_in) {  // nothing gained: the point this call started from stands (it may know more: its step state)
+        rec = resume_record(from);
+    } else if (o.O != 0 && !(a.flags & 0x4000u)) {
+        lz_flush(L, o, true, lane);
+        rec = make_uint4(hdr_bit, leave_bit, o.O, (o.adler_b << 16) | o.adler_a);
+    }
+    return false;
+#undef LZ_LEAVE
 }
 #ifndef FDH_LZ_WAVES_PER_EU
 #define FDH_LZ_WAVES_PER_EU ((FDH_LZ_WAVES_PER_CU + 3) / 4)
