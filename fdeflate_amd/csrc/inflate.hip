@@ -525,7 +525,7 @@ struct CanonLds {
     WaveIo io[kCanonWaves];
 };
 
-__global__ __launch_bounds__(kCanonWaves* kWave) void inflate_canon_kernel(InflateBatchArgs a) {
+__global__ __launch_bounds__(kCanonWaves* kWave, 4) void inflate_canon_kernel(InflateBatchArgs a) {
     __shared__ CanonLds lds;
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x / kWave;
