@@ -328,7 +328,9 @@ def test_segment_kernel_alone_short_and_unaligned(harness):
         assert guards_ok, "a segment-parallel kernel wrote outside a slot (flags %#x)" % flags
         taken = 0
         for i, name in enumerate(names):
-            assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
+            assert int(st[i]) in (0, 15, 0xFFFFFFFF), (name, int(st[i]))
+            if int(st[i]) == 15:  # (a wrong trailer behind a stream that decoded to its end: classified on the spot)
+                assert rs[i] == 15, (name, "reported WrongChecksum, reference says", ob.STATUS_NAMES[rs[i]])
             if int(st[i]) == 0:
                 taken += 1
                 assert rs[i] == 0, (name, "reported Ok, reference says", ob.STATUS_NAMES[rs[i]])
@@ -379,9 +381,13 @@ def test_segment_kernel_random_stress(harness):
         st, ln, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=flags)
         assert guards_ok
         for i, name in enumerate(names):
-            assert int(st[i]) in (0, 0xFFFFFFFF), (name, int(st[i]))
+            # (Ok, left for the kernels behind, or -- round 4 -- WrongChecksum: a stream decoded to its end whose
+            #  trailer is there and differs is classified on the spot)
+            assert int(st[i]) in (0, 15, 0xFFFFFFFF), (name, int(st[i]))
             if int(st[i]) == 0:
                 assert rs[i] == 0 and int(ln[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], name
+            if int(st[i]) == 15:
+                assert rs[i] == 15, (name, rs[i])
 
 
 def test_valid_streams_ignore_adler(harness):
