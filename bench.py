@@ -371,12 +371,13 @@ def cpu_baseline(args, comp, c_off, native_so):
 # ------------------------------------------------------------------------------------------
 
 def kernel_source_sha():
-    """Hash of the kernel sources (comment-only and blank lines aside: they do not change the machine
-    code): the PMC traffic figure of profiles/ is only quoted when it was measured on exactly this code."""
+    """Hash of the kernel sources -- the .hip files and the headers they include; comment-only and blank lines
+    aside: they do not change the machine code --: the PMC traffic figure of profiles/ is only quoted when it was
+    measured on exactly this code."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fdeflate_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip", ".cpp", ".inc")):
+        if name.endswith((".h", ".hip", ".inc")):   # (the .cpp files are host code: no kernel in them)
             h.update(name.encode())
             for line in open(os.path.join(d, name), "rb").read().split(b"\n"):
                 t = line.strip()

@@ -26,7 +26,7 @@
 // hard error in the part decoded ahead is not reported early: the attempt is repeated with the exact
 // slot, whose classification is the reference's.
 // An attempt costs a few kernel launches and a round trip to the device whatever it decodes;
-// above kAlwaysBelow buffered bytes an attempt is made only once the stream has grown by 1/8 --
+// above kAlwaysBelow buffered bytes an attempt is made only once the stream has grown by 1/8 (or by kAlwaysBelow) --
 // or when the caller passes an empty `input`, which is how both the reference's test harness
 // (src/decompress/tests/test_utils.rs:70-74: chunk size 0 once the input is exhausted) and the png
 // crate's finish loop ask for whatever can still be produced.
@@ -218,8 +218,10 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     // is a decode attempt worth it?  (nothing new and not output-limited -> no)
     const bool grew = d->in_len != d->attempted_in;
     const bool flush = input_len == 0;
+    // (an attempt only decodes what is new, but costs a few launches and a round trip whatever it decodes: above
+    //  kAlwaysBelow buffered bytes one is made for every 1/8 the stream has grown, and at least every kAlwaysBelow)
     bool attempt = !d->tried || d->output_limited || (grew && (flush || d->in_len < kAlwaysBelow ||
-                                                               d->in_len >= d->attempted_in + d->attempted_in / 8));
+                                                               d->in_len >= d->attempted_in + std::min(d->attempted_in / 8, kAlwaysBelow)));
     if (d->tried && d->output_limited && room == 0) attempt = false;  // still nowhere to put a byte
     if (!attempt) return FDH_SUCCESS;  // (nothing of the prefix is left over here: that state is output-limited)
 

@@ -224,8 +224,9 @@ int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *fi
 
 /* ---- streaming decoder: `Decompressor` (src/decompress.rs:96-156, 179-342) ----------------
  * A host-side object with exactly `Decompressor::read`'s contract on HOST buffers; every bit of
- * decoding is done by fdh_inflate_batch on the device (the object keeps a device-resident copy of
- * the stream so far and a device output slot; see csrc/stream_decompressor.cpp).
+ * decoding is done by fdh_inflate_batch_resumable on the device (the object keeps a device-resident
+ * copy of the stream so far, a device output slot and the resume point of its last attempt: an attempt
+ * decodes what is new; see csrc/stream_decompressor.cpp).
  *
  *   fdh_decompressor_new            Decompressor::new()            src/decompress.rs:123
  *   fdh_decompressor_ignore_adler32 Decompressor::ignore_adler32() src/decompress.rs:154
@@ -250,8 +251,8 @@ int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *fi
  *      stops consuming once the output is full (src/decompress.rs:167-170).  A caller written against
  *      the contract ("consumed bytes must not be offered again") behaves identically.
  *   2. With more than 256 KiB of buffered input a call with NON-EMPTY input may return (input_len, 0)
- *      without a decode attempt (attempts are then made when the stream has grown by 1/8, and on every
- *      EMPTY input).  A caller must therefore conclude "truncated" (the reference's InsufficientInput,
+ *      without a decode attempt (attempts are then made when the stream has grown by 1/8 or by 256 KiB,
+ *      and on every EMPTY input).  A caller must therefore conclude "truncated" (the reference's InsufficientInput,
  *      src/decompress.rs:1135-1136) only after a read with empty input has produced nothing and
  *      is_done is still false -- which is what the reference's own harness and the png crate do at
  *      the end of their input anyway. */
