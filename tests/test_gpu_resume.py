@@ -158,3 +158,20 @@ def test_both_in_pieces_and_the_work_done(fd):
     res, outs, guards, rec = _drive(fd, comps, [x[:steps // 2] for x in in_cuts], [x[:steps // 2] for x in out_cuts])
     inside = [i for i in range(len(items)) if rec[i][0] != 0 and int(rec[i][1]) > 8 * len(comps[i]) // 4]
     assert len(inside) >= len(items) - 2, (len(inside), [(names[i], rec[i].tolist()) for i in range(len(items))])
+
+
+def test_many_streams_taken_up_at_once(fd):
+    """1 536 streams of both formats in one batch (768 with their empty room-holders: more than one stream per
+    persistent wavefront of the LZ-window kernel on the resume path), stopped twice -- a third of the input with half
+    the room, two thirds with all of it -- and finished: every byte against the raw buffers, every status Ok."""
+    from fdeflate_amd import synth
+    n = 768
+    raws = [synth.gen_stream_np(i, 20000 + 37 * (i % 50)).tobytes() for i in range(n)]
+    comps = [ob.compress_ultra_fast(r) if i % 3 == 0 else zlib.compress(r, 1 + (i % 9)) for i, r in enumerate(raws)]
+    in_cuts = [[len(c) // 3, (2 * len(c)) // 3, len(c)] for c in comps]
+    out_cuts = [[len(r) // 2, len(r), len(r)] for r in raws]
+    (ln, st, ad), outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts)
+    assert guards
+    bad = [i for i in range(n) if int(st[i]) != 0 or int(ln[i]) != len(raws[i]) or outs[i].tobytes() != raws[i]
+           or int(ad[i]) != zlib.adler32(raws[i])]
+    assert not bad, (len(bad), bad[:5], [int(st[i]) for i in bad[:5]])
