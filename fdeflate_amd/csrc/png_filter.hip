@@ -553,6 +553,12 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
 // per XCD: the stores are in that XCD's L2 once `s_waitcnt vmcnt(0)` has passed, the row above is read with
 // loads that skip the CU's own L1 (sc1), nothing is written back or invalidated.
 constexpr uint32_t kPngXcds = 8;
+// Entries of one list (one XCD, one type, one buffer): the images of an XCD at most -- an eighth of a large batch
+// (groups of 64 go round the XCDs), all of a small one (a launch of fewer than eight workgroups populates
+// fewer XCDs).
+__host__ __device__ constexpr uint64_t png_sorted_cap(uint64_t n) {
+    return n < 8192 ? (n + kWave - 1) / kWave * kWave + kWave : (n + kPngXcds * kWave - 1) / (kPngXcds * kWave) * kWave + kWave;
+}
 struct PngSortedWork {
     uint32_t ctr[kPngXcds][3][8];  // list lengths per XCD: set (r % 3) is read at row index r, set ((r + 1) % 3) filled, set ((r + 2) % 3) zeroed
     uint32_t arrived[kPngXcds][16];  // the per-XCD barrier: workgroups that have arrived, counted up for ever (one cache line each)
@@ -693,7 +699,7 @@ __global__ __launch_bounds__(kWave) void png_sorted_kernel(PngArgs a, uint32_t* 
     uint32_t* const order = work_raw + sizeof(PngSortedWork) / 4;  // order[((xcd * 2 + buf) * 5 + type) * cap + k]: image ids
     const uint32_t lane = threadIdx.x;
     const uint64_t n = a.n;
-    const uint64_t cap = (n + kPngXcds * kWave - 1) / (kPngXcds * kWave) * kWave + kWave;  // images of one XCD at most
+    const uint64_t cap = png_sorted_cap(n);
     const uint32_t rb = a.row_bytes;
     const uint64_t src_row = (uint64_t)rb + 1;
     const uint32_t me = png_xcc_id();
@@ -711,8 +717,24 @@ __global__ __launch_bounds__(kWave) void png_sorted_kernel(PngArgs a, uint32_t* 
             }
         }
     };
-    // ---- the images: sizes, the decoder's verdict, the type of row 0; groups of 64 images go round the XCDs ----
+    // ---- who is where: the XCDs that got workgroups of this launch (all eight unless the batch is tiny) ----
     if (lane == 0) __hip_atomic_fetch_add(&W->blocks[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    png_barrier<true>(&W->arrived_all, gridDim.x);
+    uint32_t npop = 0, popmask = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < kPngXcds; x++) {
+        if (png_load_sc1(&W->blocks[x]) != 0) {
+            popmask |= 1u << x;
+            npop++;
+        }
+    }
+    // the k-th populated XCD (k < npop)
+    auto nth_xcd = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {
+        uint32_t m = popmask;
+        for (uint32_t q = 0; q < k; q++) m &= m - 1;
+        return (uint32_t)__builtin_ctz(m);
+    };
+    // ---- the images: sizes, the decoder's verdict, the type of row 0; groups of 64 images go round those XCDs ----
     for (uint64_t i0 = (uint64_t)blockIdx.x * kWave; i0 < n; i0 += (uint64_t)gridDim.x * kWave) {
         const uint64_t i = i0 + lane;
         bool want = false;
@@ -730,9 +752,9 @@ __global__ __launch_bounds__(kWave) void png_sorted_kernel(PngArgs a, uint32_t* 
             }
             a.status[i] = st;
         }
-        append(want, t, (uint32_t)i, (uint32_t)((i0 / kWave) % kPngXcds), 0, 0);
+        append(want, t, (uint32_t)i, nth_xcd((uint32_t)((i0 / kWave) % npop)), 0, 0);
     }
-    png_barrier<true>(&W->arrived_all, gridDim.x);
+    png_barrier<true>(&W->arrived_all, 2 * gridDim.x);
     const uint32_t R = png_load_sc1(&W->max_rows);
     const uint32_t mates = png_load_sc1(&W->blocks[me]);  // workgroups on this XCD
     // this workgroup's place among them: the order of arrival at a counter (any order will do)
@@ -826,7 +848,7 @@ static int png_launch_sorted(const fdh::PngArgs& a_in, uint32_t bpp, hipStream_t
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, fdh::kWave, 0) != hipSuccess || per_cu <= 0) return -1;
     const uint64_t want = (a.n + fdh::kWave - 1) / fdh::kWave;  // a unit per wavefront and row index at most
     const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)per_cu * cus, std::max<uint64_t>(want, 1));
-    const size_t cap = (size_t)((a.n + fdh::kPngXcds * fdh::kWave - 1) / (fdh::kPngXcds * fdh::kWave) * fdh::kWave + fdh::kWave);
+    const size_t cap = (size_t)fdh::png_sorted_cap(a.n);
     const size_t bytes = sizeof(fdh::PngSortedWork) + (size_t)fdh::kPngXcds * 10 * cap * sizeof(uint32_t);
     uint32_t* work = nullptr;
     if (hipMallocAsync(reinterpret_cast<void**>(&work), bytes, stream) != hipSuccess) return -1;
