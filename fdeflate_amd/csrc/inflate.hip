@@ -727,8 +727,9 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
     // wavefront is after it -- 1.3 ms for 65 536 streams, all of it exposed in a batch this kernel can
     // only pass on -- so a wavefront that passed on everything it was given takes twice as many next time.
     // (with a hand-out order: its long streams, then its short ones -- what does not look canonical is not in it)
+    // (behind the landing decoder: only what that kernel listed)
     const uint32_t n_long = a.order ? uni(a.order_counts[0]) : 0u;
-    const uint32_t n32 = a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n;
+    const uint32_t n32 = a.src_list ? uni(a.src_list[0]) : (a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n);
     uint32_t cur = 0, end = 0, take = 1;
     bool took = true;
     for (;;) {
@@ -743,7 +744,9 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
             if (cur >= n32) break;
             end = min(n32, cur + take);
         }
-        took = seg2_decode(a, lds, ckpt, a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur) || took;
+        const uint32_t sid = a.src_list ? uni(a.src_list[4 + cur])
+                                        : (a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur);
+        took = seg2_decode(a, lds, ckpt, sid) || took;
         cur++;
     }
 }
@@ -965,6 +968,9 @@ __global__ __launch_bounds__(256) void resume_prepare_kernel(uint32_t* status, c
 // `resume_io` (nullable, n records of 16 bytes): where a stream that ends InsufficientInput / OutputTooLarge can be
 // taken up again; with FDH_FLAG_RESUME_IN (0x8000) also where each stream is to be taken up NOW (all zero: at its
 // first byte) -- the slot then holds the output up to that point, and only the two general kernels run.
+// inflate_seg3.hip (a translation unit of its own: it builds in a fraction of the time of this one)
+int fdh_launch_seg3(const fdh::SegArgs& sa, unsigned blocks, hipStream_t stream);
+
 extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   void* resume_io, hipStream_t stream) {
@@ -1048,12 +1054,14 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             cus = g_cu_count[ordinal & 63];
         }
         const bool seg2 = !(flags & 0x400u);
+        const bool seg3 = seg2 && !(flags & 0x10000u);  // the landing decoder in front of the interval decoder
         const unsigned s2blocks = std::min((unsigned)((n + fdh::kS2Waves - 1) / fdh::kS2Waves), (unsigned)cus);
         // (+ the hand-out order of the interval kernel when every wavefront gets several streams);
-        // layout: first list | 4 words: counters of stream_order_kernel | second list | order | checkpoints
+        // layout: first list | 4 words: counters of stream_order_kernel | second list | order | third list | checkpoints
         const bool ordered = seg2 && n >= 4ull * s2blocks * fdh::kS2Waves && n <= 0x7FFFFFFFull;
         const size_t list2_at = (size_t)(n + 4) + 4;
-        const size_t list_words = list2_at + (size_t)(n + 4) + (ordered ? (size_t)(2 * n) : 0);
+        const size_t list3_at = list2_at + (size_t)(n + 4) + (ordered ? (size_t)(2 * n) : 0);
+        const size_t list_words = list3_at + (seg3 ? (size_t)(n + 4) : 0);
         const size_t ckpt_bytes = seg2 ? (size_t)s2blocks * fdh::kS2Waves * fdh::kS2CkptPerWave * sizeof(uint2) : 0;
         const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);  // LZ-window kernel: persistent wavefronts
         const size_t lzck_bytes = (flags & 0x1000u) ? 0 : (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
@@ -1065,6 +1073,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         } else {
             e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
             if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 8 * sizeof(uint32_t), stream);  // counters + second header
+            if (e == hipSuccess && seg3) e = hipMemsetAsync(list + list3_at, 0, 4 * sizeof(uint32_t), stream);
             if (e != hipSuccess) {
                 (void)hipFreeAsync(list, stream);
                 return (int)e;
@@ -1088,6 +1097,16 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 }
                 sa.order = order;
                 sa.order_counts = counters;
+            }
+            if (seg3) {  // what it does not take (short streams, a chain that did not land) is listed for the interval kernel
+                sa.list = list + list3_at;
+                e = (hipError_t)fdh_launch_seg3(sa, s2blocks, stream);
+                if (e != hipSuccess || (flags & 0x20000u)) {  // (debug: the landing decoder only)
+                    (void)hipFreeAsync(list, stream);
+                    return (int)e;
+                }
+                sa.src_list = list + list3_at;
+                sa.list = list;
             }
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
             e = hipGetLastError();

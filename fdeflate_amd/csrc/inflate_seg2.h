@@ -679,7 +679,9 @@ struct S2Flat {
     }
 };
 
-// Writing pass of one stream (plan from seg2_plan).
+// Writing pass of one stream (plan from seg2_plan / seg3_plan).  IN_CAP: bytes of the input image (whole KiB are
+// requested; the landing decoder's LDS layout leaves 3 KiB for it).
+template <uint32_t IN_CAP = kS2InCap>
 __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit, uint32_t* imgA, uint32_t* imgB, const uint2* ckpt,
                                            const uint64_t sid, const S2Plan& plan) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -820,7 +822,8 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
     // -> bytes [16 l, 16 l + 16).  Whoever reads the image first waits with s2_wait_vm.  Near the ends
     // of the batch buffer the bytes take the ordinary route (zero outside the buffer).
     auto request_input = [&](const uint8_t* a0) __attribute__((always_inline)) {
-        const bool inside = a0 >= buf_lo && a0 + 4096 <= buf_hi;  // (uniform) the usual case
+        constexpr uint32_t kKiB = (IN_CAP + 1023) / 1024;
+        const bool inside = a0 >= buf_lo && a0 + 1024 * kKiB <= buf_hi;  // (uniform) the usual case
         if (inside) {
             const uint8_t* p = a0 + 16 * (uint32_t)lane;
             auto* dst = (__attribute__((address_space(3))) uint32_t*)imgA;
@@ -828,10 +831,10 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
             __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
             __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+            if (kKiB > 3) __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < (int)kKiB; i++) {
                 const uint32_t x = 16 * (uint32_t)lane + 1024 * i;
                 const SegChunk ch = seg_load(a0 + x, buf_lo, buf_hi);
                 *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(imgA) + x) = make_uint4(ch.w[0], ch.w[1], ch.w[2], ch.w[3]);
@@ -850,7 +853,7 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         const uint8_t* g0 = in + ((iv.pos0 - 2) >> 3);
         a0 = reinterpret_cast<const uint8_t*>(uni64(reinterpret_cast<uintptr_t>(g0)) & ~(uintptr_t)15);
         iv.ib = (uint32_t)(g0 - a0);  // this lane's first byte in the image
-        const bool fits = valid && iv.ib + kS2InReach <= kS2InCap && (iv.q1 - wq_) + kS2OutReach <= kS2OutCap;
+        const bool fits = valid && iv.ib + kS2InReach <= IN_CAP && (iv.q1 - wq_) + kS2OutReach <= kS2OutCap;
         const uint64_t fit_mask = __ballot(fits);
         n = fit_mask == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fit_mask);
     };

@@ -1,0 +1,61 @@
+// inflate_seg3.hip -- the landing decoder's kernel (inflate_seg3.h) and its launch.
+#include "inflate_seg3.h"
+
+namespace fdh {
+
+// Landing decoder (inflate_seg3.h) in front of the interval decoder: the same hand-out, the same writing pass,
+// its own counting pass; what it does not take is listed for the interval kernel.
+__global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArgs a) {
+    __shared__ Seg3Lds lds;
+    if (lds_offset(lds.lit) != 0) __builtin_trap();
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit2);
+        const uint4* src2 = reinterpret_cast<const uint4*>(a.canon_lit);
+        uint4* dst = reinterpret_cast<uint4*>(lds.lit);
+        uint4* dst2 = reinterpret_cast<uint4*>(lds.canon);
+        for (int i = threadIdx.x; i < kLitSize / 4; i += kS2Waves * kWave) {
+            dst[i] = src[i];
+            dst2[i] = src2[i];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    uint2* const ckpt = a.ckpt + (size_t)(blockIdx.x * kS2Waves + threadIdx.x / kWave) * kS2CkptPerWave;
+    const uint32_t n_long = a.order ? uni(a.order_counts[0]) : 0u;
+    const uint32_t n32 = a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n;
+    uint32_t cur = 0, end = 0, take = 1;
+    bool took = true;
+    for (;;) {
+        if (cur == end) {
+            take = took ? 1u : min(16u, 2 * take);
+            took = false;
+            uint32_t next = 0;
+            const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;
+            if (lane == leader) next = atomicAdd(&a.list[3], take);
+            cur = uni(next);
+            if (cur >= n32) break;
+            end = min(n32, cur + take);
+        }
+        took = seg3_decode(a, lds, ckpt, a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur) || took;
+        cur++;
+    }
+}
+
+}  // namespace fdh
+
+int fdh_launch_seg3(const fdh::SegArgs& sa, unsigned blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(fdh::inflate_seg3_kernel, dim3(blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
+    return (int)hipGetLastError();
+}
+
+#ifdef FDH_S3_DEBUG
+extern "C" int fdh_debug_s3time(uint32_t* host) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_s3time), 4096 * 16 * 4) != hipSuccess) return 2;
+    if (hipMemcpyFromSymbol(host + 4096 * 16, HIP_SYMBOL(fdh::g_s3stat), 16 * 4) != hipSuccess) return 3;
+#ifdef FDH_S2_DEBUG
+    if (hipMemcpyFromSymbol(host + 4096 * 16 + 16, HIP_SYMBOL(fdh::g_s2time), 4096 * 16 * 4) != hipSuccess) return 4;
+#endif
+    return 0;
+}
+#endif
