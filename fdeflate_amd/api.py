@@ -36,6 +36,9 @@ FLAG_SPANS = 256
 FLAG_NO_FAST_GENERAL = 512
 FLAG_NO_INTERVALS = 0x400   # tests / A-B: skip the interval kernel (inflate_seg2.h)
 FLAG_INTERVALS_ONLY = 0x800  # debug: run only the interval kernel (what it leaves stays PENDING)
+FLAG_NO_LANDING = 0x10000    # tests / A-B: skip the landing decoder (inflate_seg3.h)
+FLAG_LANDING_ONLY = 0x20000  # debug: run only the landing decoder (what it leaves stays PENDING)
+FLAG_NO_LEAN_WRITE = 0x80000  # tests / A-B: the landing decoder always takes the interval decoder's general writing pass
 
 
 class DecompressionError(Exception):

@@ -825,13 +825,38 @@ __device__ __forceinline__ void seg2_write(const SegArgs& a, const uint32_t* lit
         constexpr uint32_t kKiB = (IN_CAP + 1023) / 1024;
         const bool inside = a0 >= buf_lo && a0 + 1024 * kKiB <= buf_hi;  // (uniform) the usual case
         if (inside) {
+            // (inline asm, not __builtin_amdgcn_global_load_lds: behind the builtin the compiler waits for vmcnt(0)
+            // in front of EVERY later LDS access -- the flush of this round then sat out the whole trip to memory
+            // of the next round's input, 23 % of the writing pass in round 4's clocks; the instruction itself is
+            // the same, and the one reader of the image waits for it with s2_wait_vm)
             const uint8_t* p = a0 + 16 * (uint32_t)lane;
-            auto* dst = (__attribute__((address_space(3))) uint32_t*)imgA;
-            auto* src = (const __attribute__((address_space(1))) uint32_t*)p;
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-            if (kKiB > 3) __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+            uint32_t m0_saved;
+            if (kKiB > 3) {
+                asm volatile(
+                    "  s_mov_b32 %[sv], m0\n"
+                    "  s_mov_b32 m0, %[base]\n"
+                    "  s_nop 0\n"
+                    "  global_load_lds_dwordx4 %[p], off\n"
+                    "  global_load_lds_dwordx4 %[p], off offset:1024\n"
+                    "  global_load_lds_dwordx4 %[p], off offset:2048\n"
+                    "  global_load_lds_dwordx4 %[p], off offset:3072\n"
+                    "  s_mov_b32 m0, %[sv]\n"
+                    : [sv] "=&s"(m0_saved)
+                    : [p] "v"(p), [base] "s"(uni(ldsA))
+                    : "memory");
+            } else {
+                asm volatile(
+                    "  s_mov_b32 %[sv], m0\n"
+                    "  s_mov_b32 m0, %[base]\n"
+                    "  s_nop 0\n"
+                    "  global_load_lds_dwordx4 %[p], off\n"
+                    "  global_load_lds_dwordx4 %[p], off offset:1024\n"
+                    "  global_load_lds_dwordx4 %[p], off offset:2048\n"
+                    "  s_mov_b32 m0, %[sv]\n"
+                    : [sv] "=&s"(m0_saved)
+                    : [p] "v"(p), [base] "s"(uni(ldsA))
+                    : "memory");
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < (int)kKiB; i++) {

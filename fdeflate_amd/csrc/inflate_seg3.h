@@ -27,7 +27,7 @@
 
 namespace fdh {
 
-constexpr uint32_t kS3MinDataBits = 64 * 1024;  // shorter streams are left to the interval kernel (its segments adapt)
+constexpr uint32_t kS3MinSegBits = 1024;        // no segment shorter than this: a short stream uses fewer lanes
 constexpr uint32_t kS3Window = 256;             // bits of a segment the guessed chain walks before it is believed
 constexpr uint32_t kS3RingWords = 32;           // input ring, dwords per lane ([word][lane] layout: conflict-free)
 constexpr uint32_t kS3PeriodPairs = 16;         // pairs of look-ups between two events
@@ -49,7 +49,14 @@ __device__ uint32_t g_s3time[4096 * 16];
 #define S3STAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_s3stat[k], (uint32_t)(v)); } while (0)
 #define S3T(k) do { if (sid < 4096 && (threadIdx.x & 63) == 0) g_s3time[sid * 16 + (k)] = (uint32_t)clock64(); } while (0)
 #define S3N(k, v) do { if (sid < 4096 && (threadIdx.x & 63) == 0) g_s3time[sid * 16 + (k)] = (uint32_t)(v); } while (0)
+__device__ uint32_t g_s3wtime[4096 * 8];
+#define S3W_DECL uint32_t s3w_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long s3wt_ = clock64()
+#define S3W(k) do { const long long n_ = clock64(); s3w_[k] += (uint32_t)(n_ - s3wt_); s3wt_ = n_; } while (0)
+#define S3W_OUT do { if (sid < 4096 && (threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) g_s3wtime[sid * 8 + k_] = s3w_[k_]; } while (0)
 #else
+#define S3W_DECL do { } while (0)
+#define S3W(k) do { } while (0)
+#define S3W_OUT do { } while (0)
 #define S3STAT(k, v) do { } while (0)
 #define S3T(k) do { } while (0)
 #define S3N(k, v) do { } while (0)
@@ -120,8 +127,10 @@ __device__ __forceinline__ S3Tok s3_token(const uint32_t* canon, uint32_t w) {
 }
 
 // Counting pass of one stream.  False: not for this kernel, or left PENDING (lane 0 has listed it).
+// `lean`: the stream qualifies for seg3_write -- no run chain leaves lines out of the image, the slot is 16-B aligned,
+// the stream does not end within an input image of the end of the batch buffer.
 __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit, const uint32_t* canon, uint32_t* ring, uint2* ckpt,
-                                          const uint64_t sid, S2Plan& plan) {
+                                          const uint64_t sid, S2Plan& plan, bool& lean) {
     const int lane = threadIdx.x & (kWave - 1);
     if (sid >= a.n) return false;
 
@@ -132,8 +141,10 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     const uint8_t* in = a.in + i0;
     const uint64_t ilen = i1 - i0, ocap = o1 - o0;
     const uint8_t* const buf_hi = a.in + a.in_off[a.n];
-    bool ours = ilen < (1ull << 19) && ocap < (1ull << 24) && ilen * 8 >= (uint64_t)a.canon_bits + kS3MinDataBits &&
-                in + ilen + kS3TailGuard <= buf_hi;
+    bool ours = ilen < (1ull << 19) && ocap < (1ull << 24) && ilen * 8 >= (uint64_t)a.canon_bits + 44;
+    // (uniform) a lane may load kS3TailGuard bytes past the end of its stream: the last stream(s) of the batch take the
+    // range-checked loads
+    const bool edge = in + ilen + kS3TailGuard > buf_hi;
     if (ours) {  // canonical prefix: lane k compares stream dword k
         bool mismatch = false;
         if (lane < 14) {
@@ -153,46 +164,58 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     const uint32_t in_bits = (uint32_t)(ilen * 8);
     const uint32_t cap = (uint32_t)ocap;
     const uint32_t data_bits = in_bits - a.canon_bits;
-    const uint32_t seg = (data_bits + kWave - 1) / kWave;
-    const uint32_t seg_bit0 = a.canon_bits + (uint32_t)lane * seg;
+    const uint32_t nseg = min((uint32_t)kWave, max(1u, data_bits / kS3MinSegBits));
+    const uint32_t seg = (data_bits + nseg - 1) / nseg;
+    const int last = (int)nseg - 1;                       // the lane whose chain ends on the end-of-block code
+    const bool in_range = (uint32_t)lane < nseg;          // (the other lanes idle: their reader sits on segment 0)
+    const uint32_t seg_bit0 = a.canon_bits + (in_range ? (uint32_t)lane * seg : 0u);
 
     // ---- the reader: a ring of 32 dwords per lane, the window two bits in front of the next token ----
     const uint32_t rb = lds_offset(ring) + 4 * (uint32_t)lane;
     uint32_t* const rl = ring + lane;  // word w of this lane: rl[(w & 31) * 64]
-    const uint32_t wbit = seg_bit0 - 2;
     const uint8_t* gp;
-    uint32_t Rw, Ww, lo, hi, c;
-    {
-        const uint8_t* addr = in + (wbit >> 3);
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(addr) & 15);
-        gp = addr - mis;
-        Rw = mis >> 2;
-        c = 8 * (mis & 3) + (wbit & 7);
-    }
-    const uint32_t base_tok = 8 * (uint32_t)(gp - in) + 2;  // token position = base_tok + 32 Rw + (c & 63)
-    {
-        uint4 q[8];
+    uint32_t Rw, Ww, lo, hi, c, base_tok;  // token position = base_tok + 32 Rw + (c & 63)
+    uint4 pd0, pd1, pd2, pd3;              // the 64 B requested a period ago
+    auto ld16 = [&](const uint8_t* p) __attribute__((always_inline)) {
+        if (!edge) return *reinterpret_cast<const uint4*>(p);
+        const SegChunk ch = seg_load(p, a.in, buf_hi);
+        return make_uint4(ch.w[0], ch.w[1], ch.w[2], ch.w[3]);
+    };
+    // puts the reader of the lanes in `mk` on the token at stream bit `tok`: 128 B into the ring, 64 B requested
+    auto start_reader = [&](bool mk, uint32_t tok) __attribute__((always_inline)) {
+        if (mk) {
+            const uint32_t wbit = tok - 2;
+            const uint8_t* addr = in + (wbit >> 3);
+            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(addr) & 15);
+            gp = addr - mis;
+            Rw = mis >> 2;
+            c = 8 * (mis & 3) + (wbit & 7);
+            base_tok = 8 * (uint32_t)(gp - in) + 2;
+            uint4 q[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) q[k] = reinterpret_cast<const uint4*>(gp)[k];
+            for (int k = 0; k < 8; k++) q[k] = ld16(gp + 16 * k);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            rl[(4 * k + 0) * 64] = q[k].x;
-            rl[(4 * k + 1) * 64] = q[k].y;
-            rl[(4 * k + 2) * 64] = q[k].z;
-            rl[(4 * k + 3) * 64] = q[k].w;
+            for (int k = 0; k < 8; k++) {
+                rl[(4 * k + 0) * 64] = q[k].x;
+                rl[(4 * k + 1) * 64] = q[k].y;
+                rl[(4 * k + 2) * 64] = q[k].z;
+                rl[(4 * k + 3) * 64] = q[k].w;
+            }
+            gp += 128;
+            Ww = 32;
+            pd0 = ld16(gp);
+            pd1 = ld16(gp + 16);
+            pd2 = ld16(gp + 32);
+            pd3 = ld16(gp + 48);
+            gp += 64;
         }
-        gp += 128;
-        Ww = 32;
-    }
-    uint4 pd0, pd1, pd2, pd3;  // the 64 B requested a period ago
-    pd0 = reinterpret_cast<const uint4*>(gp)[0];
-    pd1 = reinterpret_cast<const uint4*>(gp)[1];
-    pd2 = reinterpret_cast<const uint4*>(gp)[2];
-    pd3 = reinterpret_cast<const uint4*>(gp)[3];
-    gp += 64;
-    wave_sync();
-    lo = rl[(Rw & 31) * 64];
-    hi = rl[((Rw + 1) & 31) * 64];
+        wave_sync();
+        if (mk) {
+            lo = rl[(Rw & 31) * 64];
+            hi = rl[((Rw + 1) & 31) * 64];
+        }
+    };
+    start_reader(true, seg_bit0);
 
     auto position = [&]() __attribute__((always_inline)) { return base_tok + 32 * Rw + (c & 63u); };
     auto group = [&](uint32_t pairs) __attribute__((always_inline)) {
@@ -220,7 +243,7 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     {
         const uint32_t leave = seg_bit0 + kS3Window;
         for (int iter = 0; iter < 64; iter++) {
-            const bool act = lane > 0 && pos < leave;
+            const bool act = in_range && lane > 0 && pos < leave;
             if (!__any(act)) break;
             uint32_t e = 1;
             if (act) e = group(kS2Pairs);
@@ -234,16 +257,17 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
         }
     }
     S3T(3);
-    bool fault = lane > 0 && pos < seg_bit0 + kS3Window;  // (64 groups did not leave the window: cannot happen)
-    const uint32_t x0 = pos;
-    const uint32_t nxt = __shfl_down(x0, 1, kWave);
-    const uint32_t target = lane == kWave - 1 ? in_bits : nxt;
+    bool fault = in_range && lane > 0 && pos < seg_bit0 + kS3Window;  // (64 groups did not leave the window: cannot happen)
+    uint32_t start = pos;   // where the lane's counted chain starts (round 0: where its guessed chain left the window)
+    uint32_t target = 0;    // ... and where it must end: the start of the lane to its right
 
     // ---- the counted chain: from x0 to exactly `target`; checkpoints in the lane's column of the scratch ----
     uint2* const ckrow = ckpt + (uint32_t)lane;
     uint32_t slot = kS2HeadSlots, m = 0, bl = 0, eob_bits = 0;
-    bool stopped = false;
-    c &= 63u;
+    bool stopped = !in_range;
+    bool over = false;    // the chain has passed the target: no token ends there, the right neighbour's guess was wrong
+    bool landed = !in_range;
+    bool need = in_range;  // lanes that count in this round (the first: all; then the right neighbours of chains that went over)
     auto cut = [&](bool doit) __attribute__((always_inline)) {
         if (doit) {
             if (slot >= kS2Slots) {
@@ -267,111 +291,150 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
             p[8 * 64] = pd2.x; p[9 * 64] = pd2.y; p[10 * 64] = pd2.z; p[11 * 64] = pd2.w;
             p[12 * 64] = pd3.x; p[13 * 64] = pd3.y; p[14 * 64] = pd3.z; p[15 * 64] = pd3.w;
             Ww += 16;
-            pd0 = reinterpret_cast<const uint4*>(gp)[0];
-            pd1 = reinterpret_cast<const uint4*>(gp)[1];
-            pd2 = reinterpret_cast<const uint4*>(gp)[2];
-            pd3 = reinterpret_cast<const uint4*>(gp)[3];
+            pd0 = ld16(gp);
+            pd1 = ld16(gp + 16);
+            pd2 = ld16(gp + 32);
+            pd3 = ld16(gp + 48);
             gp += 64;
         }
     };
     // the run chains of the lanes in `mask` (they sit on a token that is no literal); a chain ends its interval
     auto special = [&](bool mask) __attribute__((always_inline)) {
         refill();  // (a period may have used up what the last event guaranteed; the chain reads on)
-        bool go = mask;
-        uint32_t chain = 0;
-        for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
+        // chain after chain while a lane sits on run tokens (a flat stretch is nothing else): each one its own interval
+        bool more = mask;
+        for (int nch = 0; nch < 48 && __any(more); nch++) {
+            bool go = more;
+            uint32_t chain = 0;
+            for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
+                const S3Tok t = s3_token(canon, window30());
+                const bool is_run = go && t.run != 0 && !t.bad;
+                const bool is_eob = go && rep == 0 && t.eob && lane == last;
+                over = over || (is_run && pos + t.used > target);
+                if (go && rep == 0 && nch == 0 && !is_run && !is_eob) fault = true;
+                if (is_eob) {
+                    stopped = true;
+                    eob_bits = t.used;
+                }
+                chain += is_run ? t.run : 0u;
+                advance(is_run ? t.used : 0u);
+                pos = position();
+                go = is_run && t.run == 258 && pos < target;
+            }
+            c += chain << 6;
+            bl += chain >= kS2LongRun ? chain / 16 - 1 : 0u;
+            cut(more && chain != 0);
+            // on to the next chain only where the lane sits on a run token again (anything else: back to the look-ups)
             const S3Tok t = s3_token(canon, window30());
-            const bool is_run = go && t.run != 0 && !t.bad && pos + t.used <= target;
-            const bool is_eob = go && rep == 0 && t.eob && lane == kWave - 1;
-            if (go && rep == 0 && !is_run && !is_eob) fault = true;
-            if (is_eob) {
-                stopped = true;
-                eob_bits = t.used;
-            }
-            chain += is_run ? t.run : 0u;
-            advance(is_run ? t.used : 0u);
-            pos = position();
-            go = is_run && t.run == 258 && pos < target;
+            more = more && chain != 0 && !stopped && !fault && pos < target && t.run != 0 && !t.bad;
+            if (__any(more)) refill();
         }
-        c += chain << 6;
-        bl += chain >= kS2LongRun ? chain / 16 - 1 : 0u;
-        cut(mask && chain != 0);
     };
-    cut(true);
-    uint32_t dbg_periods = 0, dbg_special = 0;
-    (void)dbg_periods;
-    (void)dbg_special;
-    // whole periods
-    for (;;) {
-        refill();
-        const bool bulk = !stopped && !fault && pos + kS3PeriodBits <= target;
-        if (!__any(bulk)) break;
-        cut(bulk && m > 0);
-        uint32_t e = 1;
-        if (bulk) {
-            m = 2 * kS3PeriodPairs;
-            e = group(kS3PeriodPairs);
+    for (int round = 0; round < 4 && __any(need); round++) {
+        {
+            const uint32_t nxt = __shfl_down(start, 1, kWave);
+            target = lane == last ? in_bits : nxt;
         }
-        pos = position();
-        const bool parked = bulk && e == 0;
-        dbg_periods++;
-        if (__any(parked)) {
-            dbg_special++;
-            special(parked);
+        if (need) {
+            slot = kS2HeadSlots;
+            m = 0;
+            bl = 0;
+            c &= 63u;
+            over = false;
+            if (round > 0) {  // what the chain from the wrong start ran into (a stray end-of-block code, a bad token) is void
+                stopped = false;
+                fault = false;
+                eob_bits = 0;
+            }
         }
-    }
-    S3T(4);
-    S3N(10, dbg_periods);
-    S3N(11, dbg_special);
-    // groups, pairs
-#pragma unroll
-    for (int stage = 0; stage < 2; stage++) {
-        const uint32_t pairs = stage == 0 ? kS2Pairs : 1u;
-        const uint32_t bits = 2 * pairs * kLitBits;
+        cut(need);
+        uint32_t dbg_periods = 0, dbg_special = 0;
+        (void)dbg_periods;
+        (void)dbg_special;
+        // whole periods
         for (;;) {
-            const bool act = !stopped && !fault && pos + bits <= target;
-            if (!__any(act)) break;
-            cut(act && m + 2 * pairs > kS2Meter);
+            refill();
+            const bool bulk = need && !stopped && !fault && pos + kS3PeriodBits <= target;
+            if (!__any(bulk)) break;
+            cut(bulk && m > 0);
             uint32_t e = 1;
-            if (act) {
-                m += 2 * pairs;
-                e = group(pairs);
+            if (bulk) {
+                m = 2 * kS3PeriodPairs;
+                e = group(kS3PeriodPairs);
             }
             pos = position();
-            const bool parked = act && e == 0;
-            if (__any(parked)) special(parked);
+            const bool parked = bulk && e == 0;
+            dbg_periods++;
+            if (__any(parked)) {
+                dbg_special++;
+                special(parked);
+            }
         }
-    }
-    S3T(5);
-    // single steps; the first literal alone once the whole step would pass the target
-    for (int iter = 0; iter < 64; iter++) {
-        const bool act = !stopped && !fault && pos < target;
-        if (!__any(act)) break;
-        const uint32_t w = window30();
-        const uint32_t e = lit[w & (kLitSize - 1)];
-        const bool spec = act && e == 0;
-        const bool step = act && e != 0;
-        cut(step && m + 1 > kS2Meter);
-        m += step ? 1u : 0u;
-        const uint32_t used = e & 15u, d = target - pos;
-        const uint32_t len1 = canon[w & (kLitSize - 1)] >> 24;
-        const bool full = step && used <= d;
-        const bool one = step && !full && len1 <= d;
-        if (step && !full && !one) fault = true;  // no token ends on the target: the neighbour's guess was wrong
-        c += (full ? (e >> 6) & 3u : (one ? 1u : 0u)) << 6;
-        advance(full ? used : (one ? len1 : 0u));
-        pos = position();
-        if (__any(spec)) special(spec);
+        S3T(4);
+        S3N(10, dbg_periods);
+        S3N(11, dbg_special);
+        // groups, pairs
+    #pragma unroll
+        for (int stage = 0; stage < 2; stage++) {
+            const uint32_t pairs = stage == 0 ? kS2Pairs : 1u;
+            const uint32_t bits = 2 * pairs * kLitBits;
+            for (;;) {
+                const bool act = need && !stopped && !fault && pos + bits <= target;
+                if (!__any(act)) break;
+                cut(act && m + 2 * pairs > kS2Meter);
+                uint32_t e = 1;
+                if (act) {
+                    m += 2 * pairs;
+                    e = group(pairs);
+                }
+                pos = position();
+                const bool parked = act && e == 0;
+                if (__any(parked)) special(parked);
+            }
+        }
+        S3T(5);
+        // single steps; the first literal alone once the whole step would pass the target
+        for (int iter = 0; iter < 64; iter++) {
+            const bool act = need && !stopped && !fault && pos < target;
+            if (!__any(act)) break;
+            const uint32_t w = window30();
+            const uint32_t e = lit[w & (kLitSize - 1)];
+            const bool spec = act && e == 0;
+            const bool step = act && e != 0;
+            cut(step && m + 1 > kS2Meter);
+            m += step ? 1u : 0u;
+            const uint32_t used = e & 15u, d = target - pos;
+            const uint32_t len1 = canon[w & (kLitSize - 1)] >> 24;
+            const bool one = step && used > d && len1 <= d;
+            const bool full = step && !one;  // (also the step that goes over: no token ends on the target)
+            over = over || (full && used > d);
+            c += (full ? (e >> 6) & 3u : (one ? 1u : 0u)) << 6;
+            advance(full ? used : (one ? len1 : 0u));
+            pos = position();
+            if (__any(spec)) special(spec);
+        }
+        if (need) landed = !fault && (lane == last ? stopped : (!stopped && (pos == target || over)));
+        cut(need && (m > 0 || slot == kS2HeadSlots + 1));  // the end of the chain is a checkpoint too (unless a cut just made it one)
+        // a chain that went over its target: the lane to its right counts again, from where that chain ended
+        const uint32_t lpos = __shfl_up(pos, 1, kWave);
+        const bool lover = __shfl_up((uint32_t)(need && over && !fault), 1, kWave) != 0;
+        need = in_range && lane > 0 && lover;
+        S3STAT(3, __popcll(__ballot(need)));
+        if (__any(need)) {
+            if (need) {
+                start = lpos;
+                landed = false;
+            }
+            start_reader(need, lpos);
+            pos = position();
+        }
     }
     S3T(6);
-    const bool landed = !fault && (lane == kWave - 1 ? stopped : (!stopped && pos == target));
-    cut(m > 0 || slot == kS2HeadSlots + 1);  // the end of the chain is a checkpoint too (unless a cut just made it one)
-
     // ---- the plan ----
-    bool ok = !__any(!landed) && !__any(fault);
-    const uint32_t count = c >> 6;
-    const uint32_t n_int = slot - kS2HeadSlots - 1;
-    ok = ok && !__any(slot < kS2HeadSlots + 2);
+    bool ok = !__any(!landed) && !__any(fault) && !__any(need);
+    const uint32_t count = in_range ? c >> 6 : 0u;
+    const uint32_t n_int = in_range ? slot - kS2HeadSlots - 1 : 0u;
+    ok = ok && !__any(in_range && slot < kS2HeadSlots + 2);
     unsigned long long incl = count;
     uint32_t incl_b = bl, incl_n = n_int;
 #pragma unroll
@@ -388,7 +451,7 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
                                        __builtin_amdgcn_readlane((uint32_t)incl, kWave - 1);
     ok = ok && total64 <= cap;
     ok = ok && __builtin_amdgcn_readlane(incl_b, kWave - 1) < (1u << (32 - kS2PosBits));
-    const uint32_t eob_end = __builtin_amdgcn_readlane(pos + eob_bits, kWave - 1);
+    const uint32_t eob_end = __builtin_amdgcn_readlane(pos + eob_bits, last);
     const uint32_t tb = (eob_end + 7) >> 3;
     ok = ok && (uint64_t)tb * 8 + 32 <= in_bits;
     S3STAT(0, 1);
@@ -409,7 +472,256 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     plan.ni = __builtin_amdgcn_readlane(incl_n, kWave - 1);
     plan.tb = tb;
     plan.seg = seg;
+    lean = !(a.flags & 0x80000u) && __builtin_amdgcn_readlane(incl_b, kWave - 1) == 0 &&
+           ((reinterpret_cast<uintptr_t>(a.out) + o0) & 15) == 0 && in + ilen + kS3InCap + 128 <= buf_hi;
     S3T(7);
+    return true;
+}
+
+// Lean writing pass: the rounds of seg2_write for a stream whose run chains all stay inside the image (no bulk
+// lines, no breaks) and whose slot is 16-B aligned -- every PNG-filter stream of the ultra-fast encoder with noisy
+// rows.  A round is an order of magnitude fewer instructions around the look-up group than the general writer's:
+//   * a run chain is decoded from the reference-layout table in the LDS (s3_token) and, being a run of zeros --
+//     all the reference's encoder ever emits (src/compress/ultrafast.rs:46-66) --, leaves the zero-initialised
+//     image as it is; a run of anything else sends the stream to the general writers behind this kernel;
+//   * image positions are output positions, the Adler-32 terms are 32-bit sums and one 64-bit multiply-add per piece;
+//   * the next round's input image is requested as soon as this round has decoded (the request is inline asm: the
+//     compiler does not wait for it in front of the LDS reads of the flush), the flush comes behind it.
+// False: the stream was left PENDING.
+__device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit, const uint32_t* canon, uint32_t* imgA, uint32_t* imgB,
+                                           const uint2* ckpt, const uint64_t sid, const S2Plan& plan) {
+    const uint32_t total = uni(plan.total), ni = uni(plan.ni), tb = uni(plan.tb), seg = uni(plan.seg);
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint8_t* in = a.in + a.in_off[sid];
+    uint8_t* const op = a.out + a.out_off[sid];
+    const uint32_t ldsA = lds_offset(imgA), ldsB = lds_offset(imgB);
+    uint8_t* const imgB8 = reinterpret_cast<uint8_t*>(imgB);
+    uint32_t f0 = 0, qa = 0;
+    uint32_t ad_a = 0, ad_u = 0;
+    unsigned long long ad_b = 0;
+    bool bad = false;
+    for (uint32_t x = 16 * (uint32_t)lane; x < kS2OutCap; x += 16 * kWave)
+        *reinterpret_cast<uint4*>(imgB8 + x) = make_uint4(0, 0, 0, 0);
+
+    // The intervals of a round: interval f belongs to the last lane whose P <= f (binary search over the lanes' P
+    // by ds_bpermute); its two checkpoints are requested, what turns them into stream bits / output bytes is kept.
+    struct Fetch {
+        uint2 e0, e1;
+        uint32_t pbase, qbase;
+        bool valid;
+    };
+    auto fetch = [&](uint32_t fbase) __attribute__((always_inline)) {
+        Fetch t;
+        const uint32_t f = fbase + (uint32_t)lane;
+        t.valid = f < ni;
+        uint32_t sg = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const uint32_t probe = sg + step;
+            const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((probe & 63) << 2), (int)plan.P);
+            if (probe < (uint32_t)kWave && pv <= f) sg = probe;
+        }
+        const uint32_t sP = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.P);
+        t.qbase = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.obase);
+        t.pbase = a.canon_bits + sg * seg;
+        const uint32_t slot = kS2HeadSlots + (f - sP);
+        t.e0 = t.e1 = make_uint2(0, 0);
+        if (t.valid) {
+            t.e0 = ckpt[S2_CK_AT(sg, slot)];
+            t.e1 = ckpt[S2_CK_AT(sg, slot + 1)];
+        }
+        return t;
+    };
+    // the intervals of the round in c0 (start) / c1 (end): x = stream bit of the first token, y = output bytes in
+    // front of it; how many of them fit the two images: n
+    uint2 c0, c1;
+    bool valid;
+    auto settle = [&](const Fetch& t) __attribute__((always_inline)) {
+        const uint32_t posmask = (1u << kS2PosBits) - 1;
+        c0 = make_uint2(t.pbase + (t.e0.x & posmask), t.qbase + t.e0.y);
+        c1 = make_uint2(t.pbase + (t.e1.x & posmask), t.qbase + t.e1.y);
+        valid = t.valid;
+    };
+    settle(fetch(0));
+    uint32_t n = 0, ib = 0;
+    const uint8_t* a0 = in;
+    auto stage_c = [&](uint32_t wq_) __attribute__((always_inline)) {
+        const uint8_t* g0 = in + ((c0.x - 2) >> 3);
+        a0 = reinterpret_cast<const uint8_t*>(uni64(reinterpret_cast<uintptr_t>(g0)) & ~(uintptr_t)15);
+        ib = (uint32_t)(g0 - a0);
+        const bool fits = valid && ib + kS2InReach <= kS3InCap && (c1.y - wq_) + kS2OutReach <= kS2OutCap;
+        const uint64_t fit_mask = __ballot(fits);
+        n = fit_mask == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fit_mask);
+    };
+    auto request = [&](const uint8_t* from) __attribute__((always_inline)) {
+        const uint8_t* p = from + 16 * (uint32_t)lane;
+        uint32_t m0_saved;
+        asm volatile(
+            "  s_mov_b32 %[sv], m0\n"
+            "  s_mov_b32 m0, %[base]\n"
+            "  s_nop 0\n"
+            "  global_load_lds_dwordx4 %[p], off\n"
+            "  global_load_lds_dwordx4 %[p], off offset:1024\n"
+            "  global_load_lds_dwordx4 %[p], off offset:2048\n"
+            "  s_mov_b32 m0, %[sv]\n"
+            : [sv] "=&s"(m0_saved)
+            : [p] "v"(p), [base] "s"(uni(ldsA))
+            : "memory");
+    };
+    stage_c(qa - 16);
+    wave_sync();  // (the counting pass is done with this LDS)
+    request(a0);
+    uint32_t stores_behind = 0;
+    S3W_DECL;
+    while (f0 < ni) {
+        S3W(7);
+        const uint32_t wq = qa - 16;  // (mod 2^32: the image starts one piece in front of what has not been flushed)
+        if (n == 0) {
+            bad = true;
+            break;
+        }
+        const bool act = (uint32_t)lane < n;
+        const uint32_t pos0 = c0.x, pos1 = c1.x, q0 = c0.y;
+        const uint32_t in_off0 = (uint32_t)(a0 - in), ib_cur = ib;
+        const uint32_t qf_new = __builtin_amdgcn_readlane(c1.y, (int)(n - 1));
+        // ---- the next round's intervals are on their way while this one decodes ----
+        const Fetch nx = fetch(f0 + n);
+        S3W(0);
+        // ---- the input image (requested a round ago; the flush's stores and the two loads above came later) ----
+        s2_wait_vm(stores_behind + (f0 + n < ni ? 2u : 0u));
+        wave_sync();
+        uint32_t wi = act ? (ib_cur >> 2) + 2 : 2u;
+        uint32_t lo = imgA[wi - 2], hi = imgA[wi - 1];
+        uint32_t boff = 8 * (ib_cur & 3) + ((pos0 - 2) & 7);
+        uint32_t oaddr = ldsB + (q0 - wq);
+        S3W(1);
+        {
+            uint32_t c = boff | (oaddr << 6), acc = 0, ra = ldsA + 4 * wi;
+            if (act) (void)seg2_write_group(kS2Meter / 2, lo, hi, c, ra, acc);
+            wi = (ra - ldsA) >> 2;
+            boff = c & 63u;
+            oaddr = c >> 6;
+        }
+        // (the checkpoints asked for above have had the whole group to arrive; taking them HERE keeps the compiler from
+        // waiting for them -- and with them for this round's stores and the next input image -- at the loop's head)
+        S3W(2);
+        asm volatile("" ::"v"(nx.e0.x), "v"(nx.e0.y), "v"(nx.e1.x), "v"(nx.e1.y));
+        uint32_t pos = 8 * (in_off0 + 4 * (wi - 2)) + boff + 2;  // stream bit of the lane's next token
+        // ---- a lane that is not at the end of its interval sits on the run chain that ends it ----
+        bool go = act && pos < pos1;
+        if (__any(go)) {
+            const bool mine = go;
+            uint32_t chain = 0;
+            for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
+                const S3Tok t = s3_token(canon, __builtin_amdgcn_alignbit(hi, lo, boff) >> 2);
+                const bool step = go && t.run != 0 && !t.bad;
+                bad = bad || (go && rep == 0 && !step);
+                chain += step ? t.run : 0u;
+                const uint32_t adv = step ? t.used : 0u;
+                pos += adv;
+                boff += adv;
+                const bool wrap = boff >= 32;
+                const uint32_t nw = imgA[wi];
+                lo = wrap ? hi : lo;
+                hi = wrap ? nw : hi;
+                wi += wrap ? 1u : 0u;
+                boff &= 31u;
+                go = step && t.run == 258 && pos < pos1;
+            }
+            wave_sync();
+            const uint32_t xi = mine ? oaddr - ldsB : 16u;
+            const uint32_t front = imgB8[xi - 1];
+            bad = bad || (mine && (pos != pos1 || front != 0 || chain >= kS2LongRun || wq + xi == 0));
+        }
+        if (__any(bad)) {
+            bad = true;
+            break;
+        }
+        wave_sync();
+        S3W(3);
+        const bool final_round = f0 + n >= ni;
+        const uint32_t qa_new = final_round ? (qf_new + 15) & ~15u : max(qa, qf_new & ~127u);
+        const uint32_t xa_new = qa_new - wq, n_cur = n;
+        // ---- the next round: its intervals, how many fit, its input bytes (this round is done with the image) ----
+        settle(nx);
+        if (!final_round) {
+            stage_c(qa_new - 16);
+            request(a0);
+        }
+        stores_behind = final_round ? 64u : (xa_new - 16 + 1023) / 1024;
+        S3W(4);
+        // ---- flush: whole 128-B lines of the image (everything once the stream ends), one store per KiB ----
+        for (uint32_t x = 16 + 16 * (uint32_t)lane; __any(x < xa_new); x += 16 * kWave) {
+            const uint32_t v = wq + x;
+            if (x < xa_new && v + 16 <= total) {
+                const uint4 q = *reinterpret_cast<const uint4*>(imgB8 + x);
+                *reinterpret_cast<uint4*>(op + v) = q;
+                uint32_t sum = bytesum4(q.x);
+                sum = __builtin_amdgcn_sad_u8(q.y, 0u, sum);
+                sum = __builtin_amdgcn_sad_u8(q.z, 0u, sum);
+                sum = __builtin_amdgcn_sad_u8(q.w, 0u, sum);
+                ad_u = bytedot4(q.x, 0x03020100u, ad_u);
+                ad_u = bytedot4(q.y, 0x07060504u, ad_u);
+                ad_u = bytedot4(q.z, 0x0b0a0908u, ad_u);
+                ad_u = bytedot4(q.w, 0x0f0e0d0cu, ad_u);
+                ad_a += sum;
+                ad_b += (unsigned long long)(total - v) * sum;
+            }
+        }
+        S3W(5);
+        if (final_round) {
+            if (total & 15u) {  // the last piece of the stream: its own bytes only
+                const uint32_t v = total & ~15u, x = v - wq;
+                if ((uint32_t)lane == (((x - 16) >> 4) & 63u)) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(imgB8 + x);
+                    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                    for (uint32_t kk = 0; kk < (total & 15u); kk++) {
+                        const uint32_t byte = (w[kk >> 2] >> (8 * (kk & 3))) & 0xFFu;
+                        op[v + kk] = (uint8_t)byte;
+                        ad_a += byte;
+                        ad_b += (unsigned long long)(total - v - kk) * byte;
+                    }
+                }
+            }
+        } else {
+            // ---- carry: the pieces from one below qa_new on move to the front of the image, the rest is zeroed ----
+            const uint32_t src0 = xa_new - 16;
+            const uint32_t keep_end = ((qf_new + 15) & ~15u) - wq;
+            const uint32_t used_end = min(kS2OutCap, (keep_end + kS2OutReach + 15) & ~15u);
+            const uint32_t sx = src0 + 16 * (uint32_t)lane;
+            uint4 keep = make_uint4(0, 0, 0, 0);
+            if (sx < keep_end) keep = *reinterpret_cast<const uint4*>(imgB8 + sx);
+            wave_sync();  // every lane has read before any lane writes
+            *reinterpret_cast<uint4*>(imgB8 + 16 * (uint32_t)lane) = keep;
+            for (uint32_t x = 16 * (uint32_t)(lane + kWave); x < used_end; x += 16 * kWave)
+                *reinterpret_cast<uint4*>(imgB8 + x) = make_uint4(0, 0, 0, 0);
+            wave_sync();
+        }
+        qa = qa_new;
+        f0 += n_cur;
+        S3W(6);
+    }
+    S3W_OUT;
+    if (__any(bad)) {
+        if (lane == 0) seg_leave_pending(a, sid);
+        return false;
+    }
+    // ---- Adler-32: A = 1 + sum of bytes ; B = total + sum of (total - offset) x byte ----
+    uint32_t pa = ad_a % kAdlerMod;
+    uint32_t pb = (uint32_t)((ad_b - ad_u) % kAdlerMod);
+    pa = wave_sum_u32(pa);
+    pb = wave_sum_u32(pb);
+    const uint32_t A = (1u + pa) % kAdlerMod;
+    const uint32_t B = (uint32_t)(((uint64_t)total + pb) % kAdlerMod);
+    const uint32_t adler = (B << 16) | A;
+    if (lane == 0) {
+        // src/decompress.rs:306-326: byte boundary, then the big-endian Adler-32; Ok / WrongChecksum is the comparison
+        // (every token was decoded and the trailer is there: see seg2_write)
+        const uint32_t stored = ((uint32_t)in[tb] << 24) | ((uint32_t)in[tb + 1] << 16) | ((uint32_t)in[tb + 2] << 8) | (uint32_t)in[tb + 3];
+        a.status[sid] = (stored == adler || (a.flags & 1u)) ? (uint32_t)ST_OK : (uint32_t)ST_WRONG_CHECKSUM;
+        a.out_len[sid] = total;
+        if (a.adler) a.adler[sid] = adler;
+    }
     return true;
 }
 
@@ -419,13 +731,17 @@ __device__ __forceinline__ bool seg3_decode(const SegArgs& a, Seg3Lds& L, uint2*
     const uint32_t wid = threadIdx.x / kWave;
     uint32_t* const W = L.w[wid];
     S2Plan plan;
-    const bool planned = seg3_plan(a, L.lit, L.canon, W, ckpt, sid, plan);
+    bool lean = false;
+    const bool planned = seg3_plan(a, L.lit, L.canon, W, ckpt, sid, plan, lean);
     // the writing pass of the interval decoder: output image in the first 5 KiB, input image in the last 3
     if (planned && (a.flags & 0x40000u)) {  // debug (FDH_FLAG_LANDING_COUNT_ONLY): time the counting pass alone
         if ((threadIdx.x & (kWave - 1)) == 0) seg_leave_pending(a, sid);
         return true;
     }
-    if (planned) seg2_write<kS3InCap>(a, L.lit, W + kS2BWords, W, ckpt, sid, plan);
+    if (planned) {
+        if (lean) (void)seg3_write(a, L.lit, L.canon, W + kS2BWords, W, ckpt, sid, plan);
+        else seg2_write<kS3InCap>(a, L.lit, W + kS2BWords, W, ckpt, sid, plan);
+    }
     S3T(8);
     return planned;
 }

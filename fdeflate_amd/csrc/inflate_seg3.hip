@@ -56,6 +56,7 @@ extern "C" int fdh_debug_s3time(uint32_t* host) {
 #ifdef FDH_S2_DEBUG
     if (hipMemcpyFromSymbol(host + 4096 * 16 + 16, HIP_SYMBOL(fdh::g_s2time), 4096 * 16 * 4) != hipSuccess) return 4;
 #endif
+    if (hipMemcpyFromSymbol(host + 4096 * 16 + 16 + 4096 * 16, HIP_SYMBOL(fdh::g_s3wtime), 4096 * 8 * 4) != hipSuccess) return 5;
     return 0;
 }
 #endif
