@@ -711,6 +711,7 @@ __global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, co
 // wavefront, one workgroup of 16 persistent wavefronts per CU with all of its LDS.
 __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArgs a) {
     __shared__ Seg2Lds lds;
+    if (a.src_list && a.src_list[0] == 0) return;  // the landing decoder left nothing over: do not even stage the table
     // the hand-scheduled loops address the table from LDS offset 0 (`raw & 0x3ffc` IS the address)
     if (lds_offset(lds.lit) != 0) __builtin_trap();
     {   // the table in this kernel's entry layout, built once per device by canon_build_kernel: a plain copy
@@ -730,7 +731,9 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
     // (behind the landing decoder: only what that kernel listed)
     const uint32_t n_long = a.order ? uni(a.order_counts[0]) : 0u;
     const uint32_t n32 = a.src_list ? uni(a.src_list[0]) : (a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n);
-    uint32_t cur = 0, end = 0, take = 1;
+    // (the first stream of a wavefront is its own number: 4 096 wavefronts after one counter at once is 80 us)
+    const uint32_t n_waves = gridDim.x * kS2Waves;
+    uint32_t cur = blockIdx.x * kS2Waves + threadIdx.x / kWave, end = cur + 1, take = 1;
     bool took = true;
     for (;;) {
         if (cur == end) {
@@ -740,10 +743,10 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
             uint32_t next = 0;
             const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;
             if (lane == leader) next = atomicAdd(&a.list[2], take);
-            cur = uni(next);
-            if (cur >= n32) break;
+            cur = uni(next) + n_waves;
             end = min(n32, cur + take);
         }
+        if (cur >= n32) break;
         const uint32_t sid = a.src_list ? uni(a.src_list[4 + cur])
                                         : (a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur);
         took = seg2_decode(a, lds, ckpt, sid) || took;
@@ -1071,9 +1074,14 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             (void)hipGetLastError();
             list = nullptr;  // fall back to the status-scan form
         } else {
-            e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
-            if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 8 * sizeof(uint32_t), stream);  // counters + second header
-            if (e == hipSuccess && seg3) e = hipMemsetAsync(list + list3_at, 0, 4 * sizeof(uint32_t), stream);
+            // the headers of the lists and the counters between them: one fill over the list words is cheaper than three
+            // small ones (a fill is a kernel of its own on the stream)
+            if (seg3 || ordered) {
+                e = hipMemsetAsync(list, 0, list_words * sizeof(uint32_t), stream);
+            } else {
+                e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
+                if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 8 * sizeof(uint32_t), stream);  // counters + second header
+            }
             if (e != hipSuccess) {
                 (void)hipFreeAsync(list, stream);
                 return (int)e;

@@ -23,7 +23,9 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArg
     uint2* const ckpt = a.ckpt + (size_t)(blockIdx.x * kS2Waves + threadIdx.x / kWave) * kS2CkptPerWave;
     const uint32_t n_long = a.order ? uni(a.order_counts[0]) : 0u;
     const uint32_t n32 = a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n;
-    uint32_t cur = 0, end = 0, take = 1;
+    // (the first stream of a wavefront is its own number: 4 096 wavefronts after one counter at once is 80 us)
+    const uint32_t n_waves = gridDim.x * kS2Waves;
+    uint32_t cur = blockIdx.x * kS2Waves + threadIdx.x / kWave, end = cur + 1, take = 1;
     bool took = true;
     for (;;) {
         if (cur == end) {
@@ -32,10 +34,10 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArg
             uint32_t next = 0;
             const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;
             if (lane == leader) next = atomicAdd(&a.list[3], take);
-            cur = uni(next);
-            if (cur >= n32) break;
+            cur = uni(next) + n_waves;
             end = min(n32, cur + take);
         }
+        if (cur >= n32) break;
         took = seg3_decode(a, lds, ckpt, a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur) || took;
         cur++;
     }
