@@ -151,22 +151,25 @@ def encode_zlib6(raw_rows, dev):
 
 
 def mix_pool(raw, uf_comp, uf_off, uf_len, rnd):
-    """The distinct streams of the mix line: (compressed, raw or None, Ok expected, what it is)."""
+    """The distinct streams of the mix line: (compressed, raw or None, Ok expected, what it is, status expected).
+    The status of a stream that is not Ok is what its maker built it for (include/fdeflate_hip.h fdh_stream_status:
+    1 BadZlibHeader, 2 InsufficientInput, 9 BadLiteralLengthHuffmanTree, 15 WrongChecksum); the three .zz vectors are
+    the reference's own (src/decompress.rs:1344-1384: a wrong checksum, two trees without an end-of-block code)."""
     import zlib
     pool = []
     gold = os.path.join(ROOT, "tests", "golden", "vectors")
     nref = 0
     for name in sorted(os.listdir(os.path.join(gold, "corpus"))):
         c = open(os.path.join(gold, "corpus", name), "rb").read()
-        pool.append((c, zlib.decompress(c), True, "corpus/" + name))
+        pool.append((c, zlib.decompress(c), True, "corpus/" + name, 0))
         nref += 1
     for name in sorted(os.listdir(gold)):
         if name.endswith(".zz"):   # (a wrong checksum, two trees without an end-of-block code: reference tests/*.zz)
             c = open(os.path.join(gold, name), "rb").read()
             try:
-                pool.append((c, zlib.decompress(c), True, name))
-            except zlib.error:
-                pool.append((c, None, False, name))
+                pool.append((c, zlib.decompress(c), True, name, 0))
+            except zlib.error as ze:
+                pool.append((c, None, False, name, 15 if "incorrect data check" in str(ze) else 9))
             nref += 1
     h = raw[:48].cpu().numpy()
     for i in range(48):
@@ -184,26 +187,26 @@ def mix_pool(raw, uf_comp, uf_off, uf_len, rnd):
             c = zlib.compress(r, 6)
         else:
             c = zlib.compress(r, 6)
-        pool.append((c, r, True, "zlib kind %d of buffer %d" % (kind, i)))
+        pool.append((c, r, True, "zlib kind %d of buffer %d" % (kind, i), 0))
     ufo = uf_off[:33].cpu().numpy()
     ufl = uf_len[:32].cpu().numpy()
     ufc = uf_comp[:int(ufo[32])].cpu().numpy()
     for i in range(32):                                               # the headline's own format
-        pool.append((ufc[int(ufo[i]):int(ufo[i]) + int(ufl[i])].tobytes(), h[i].tobytes(), True, "ultra-fast, buffer %d" % i))
+        pool.append((ufc[int(ufo[i]):int(ufo[i]) + int(ufl[i])].tobytes(), h[i].tobytes(), True, "ultra-fast, buffer %d" % i, 0))
     good = [p for p in pool if p[2] and len(p[0]) > 64]
     for k in range(24):                                               # damaged and truncated copies: never Ok
         g = good[rnd.randrange(len(good))]
         c = g[0]
         if k % 3 == 0:
-            pool.append((c[:rnd.randrange(8, len(c) - 4)], None, False, "cut short: " + g[3]))   # InsufficientInput
+            pool.append((c[:rnd.randrange(8, len(c) - 4)], None, False, "cut short: " + g[3], 2))   # InsufficientInput
         elif k % 3 == 1:
             b = bytearray(c)
             b[len(b) - 1 - rnd.randrange(4)] ^= 1 << rnd.randrange(8)      # WrongChecksum
-            pool.append((bytes(b), None, False, "trailer damaged: " + g[3]))
+            pool.append((bytes(b), None, False, "trailer damaged: " + g[3], 15))
         else:
             b = bytearray(c)
             b[0] ^= 0x07                                                   # BadZlibHeader
-            pool.append((bytes(b), None, False, "header damaged: " + g[3]))
+            pool.append((bytes(b), None, False, "header damaged: " + g[3], 1))
     return pool, nref
 
 
@@ -229,6 +232,7 @@ def build_mix(n, raw, uf_comp, uf_off, uf_len, dev):
     ooff[1:] = np.cumsum(rlen)
     check = [i for i in range(0, n, max(1, n // 97)) if pool[order[i]][2]]
     exp = {"ok": torch.tensor([pool[j][2] for j in order], dtype=torch.bool, device=dev),
+           "status": torch.tensor([pool[j][4] for j in order], dtype=torch.int32, device=dev),
            "raw": {i: pool[order[i]][1] for i in check}, "check": check,
            "what": "%d distinct: %d reference corpus / .zz vectors, 48 zlib streams of the bench's buffers (stored, fixed, RLE, "
                    "Huffman-only, levels 6 and 9, short ones), 32 ultra-fast streams, 24 damaged or truncated copies"
@@ -422,7 +426,7 @@ def roofline(alg_bytes, kern_ms, kernel, traffic):
             "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
 
-DECODE_KERNELS = ("inflate_seg2_kernel (+ inflate_segments_kernel / inflate_canon_kernel / inflate_general_fast_kernel / "
+DECODE_KERNELS = ("inflate_seg3_kernel (+ inflate_seg2_kernel / inflate_segments_kernel / inflate_canon_kernel / inflate_general_fast_kernel / "
                   "inflate_general_kernel follow-ups on what it leaves over, one fdh_inflate_batch call)")
 
 
@@ -657,7 +661,7 @@ def main():
                                          "%d streams, %d rows x %d bytes, %d bytes per pixel" % (n, rows_png, rb_png, bpp_png),
                              "metric": "decompressed GB/s", "value": round(n * L / (w4 / psteps) / 1e9, 3),
                              "ms_per_step": round(w4 * 1e3 / psteps, 4), "steps": psteps,
-                             "roofline": roofline(palg, sum(k4) / len(k4), "inflate_seg2_kernel + png_pipe_kernel",
+                             "roofline": roofline(palg, sum(k4) / len(k4), "inflate_seg3_kernel + png_pipe_kernel",
                                                   profiled_traffic("png") if full else None)})
                 # ... and the other direction: filtering fused into the ultra-fast encoder (the pixels just
                 # reconstructed, the rows' own filter types): must give the bench's compressed streams back
@@ -738,6 +742,7 @@ def main():
                 barrier()
                 ok = mst == 0
                 assert bool((ok == mexp["ok"]).all()), "mix: a stream's Ok / not-Ok differs from what its maker expects"
+                assert bool((mst == mexp["status"]).all()), "mix: the error kind of a damaged stream differs from what it was built for"
                 assert bool((mln[ok].to(torch.int64) == mraw_len[ok]).all()), "mix: length of an Ok stream"
                 for i in mexp["check"]:
                     a0 = int(mr_off[i])

@@ -166,9 +166,10 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
     StreamResult r;
     const ResumePoint rec = resume_point(a, sid, st);  // where a kernel in front left the stream
     ResumePoint rp = rec;
-    // A tile decoder in front has been over this stream and left it at its last check point for the exact
-    // serial decoder: no second pass of tiles.
-    if (st == kPendingSerial && rec.valid) tiles = false;
+    // A tile decoder in front has been over this stream and left it for the exact serial decoder: no second
+    // pass of tiles, with or without a check point to start from (without one -- no scratch for the records, or
+    // FDH_FLAG_NO_CHECKPOINTS -- the serial decoder starts at the stream's first byte).
+    if (st == kPendingSerial) tiles = false;
     if (tiles) {
         // the span decoder lists matches in global scratch: take one of the pool's slots
         uint32_t slot = kSpanSlots;
@@ -514,6 +515,9 @@ void inflate_lz_kernel(InflateBatchArgs a) {
                 a.resume[sid] = rec;
                 a.status[sid] = kPendingResume;
             }
+            // a stream this kernel finished leaves no resume point: "all zero for every other status" (with
+            // FDH_FLAG_RESUME_IN the caller's array still holds the record the stream was taken up at)
+            if (finished && a.resume_out && a.status[sid] == ST_OK) a.resume_out[sid] = make_uint4(0, 0, 0, 0);
             i = atomicAdd(a.lz_counter, 1u) + gridDim.x;
         }
         i = uni(i);
@@ -957,7 +961,7 @@ __global__ __launch_bounds__(256) void resume_prepare_kernel(uint32_t* status, c
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         const uint4 r = resume[i];
-        work[i] = r;
+        work[i] = r;  // (the caller's record stays until a final result overwrites it: general_one may need it)
         status[i] = r.x != 0 ? fdh::kPendingResume : fdh::kPending;
         scratch[8 + i] = (uint32_t)i;
     }
@@ -1010,6 +1014,10 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         e = hipGetLastError();
         (void)hipFreeAsync(scratch, stream);
         return (int)e;
+    }
+    if (resume_io) {  // (same promise for a call that starts every stream at its first byte)
+        const hipError_t e0 = hipMemsetAsync(resume_io, 0, (size_t)n * sizeof(uint4), stream);
+        if (e0 != hipSuccess) return (int)e0;
     }
     if (flags & 0x100u) {  // FDH_FLAG_SPANS: scratch of the span decoder, allocated once per device, zero-initialised
         int ordinal = 0;

@@ -527,341 +527,10 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
     if (lane < cnt) a.status[img0 + lane] = my_st ? my_st : (lds.bad[lane] != 0xFFFFFFFFu ? 1u : 0u);
 }
 
-// ---- reconstruction by rows of one type per wavefront (experiment, FDH_PNG_SORTED=1) ---------------------
-//
-// The kernels above compute EVERY predictor for every byte (20 of their 33 instructions per byte): the lanes
-// of a wavefront hold rows of different filter types, and the types of the bench's rows are uniform over 0..4.
-// Here a wavefront only ever works on rows of ONE type, each lane walking a whole row: None is a copy, Up one
-// SWAR add per dword, Sub / Average a short chain per byte, only a Paeth row pays for Paeth.  The price is the
-// order: row r of an image needs row r - 1 of the same image, so the rows are taken index by index -- all rows
-// 0, then all rows 1, ... -- with the images sorted by the type of their next row: while a lane finishes row r
-// of its image it appends the image to the list of the type of row r + 1 (one aggregated atomic per type and
-// wavefront).  ONE cooperative launch; a barrier between row indices.
-// MEASURED (round 4, 65 536 images of 64 rows x 1 023 bytes, bit-exact): 16.4 ms against the pipeline's 6.1-7.4 --
-// not the default.  Where it goes: the lists and barriers alone 1.7 ms; the rows without the barriers 6.0 ms --
-// no faster than the pipeline although the arithmetic is a quarter: with a row per lane every 16 bytes are a
-// request of their own to the L2 (3 072 per wavefront and 128-byte piece: 8 loads of the filtered row, 32 dword
-// loads of the row above, 8 stores), and that is what bounds it (the same time with every access dword-aligned,
-// so it is not the rows' odd addresses); and between two barriers everybody waits for the Paeth rows (16.4 ms =
-// 64 row indices x the slowest wavefront of each).  What it would take: pieces moved by the wavefront as whole
-// lines through LDS (8 requests instead of 64 per instruction), and the Paeth rows split up.
-// The GPU's eight XCDs each have an L2 of their own, coherent with the others only through memory: a grid-wide
-// barrier that makes one CU's stores visible to every other CU has to write the L2s back and invalidate them
-// (release / acquire at agent scope) -- measured here: ~300 us per row index, 20 ms for 64 rows.  So an image
-// stays on ONE XCD: images are dealt out to the XCDs in groups of 64, every workgroup finds out which XCD it
-// runs on (HW_REG_XCC_ID) and only takes rows of that XCD's images, and the barrier between row indices is one
-// per XCD: the stores are in that XCD's L2 once `s_waitcnt vmcnt(0)` has passed, the row above is read with
-// loads that skip the CU's own L1 (sc1), nothing is written back or invalidated.
-constexpr uint32_t kPngXcds = 8;
-// Entries of one list (one XCD, one type, one buffer): the images of an XCD at most -- an eighth of a large batch
-// (groups of 64 go round the XCDs), all of a small one (a launch of fewer than eight workgroups populates
-// fewer XCDs).
-__host__ __device__ constexpr uint64_t png_sorted_cap(uint64_t n) {
-    return n < 8192 ? (n + kWave - 1) / kWave * kWave + kWave : (n + kPngXcds * kWave - 1) / (kPngXcds * kWave) * kWave + kWave;
-}
-struct PngSortedWork {
-    uint32_t ctr[kPngXcds][3][8];  // list lengths per XCD: set (r % 3) is read at row index r, set ((r + 1) % 3) filled, set ((r + 2) % 3) zeroed
-    uint32_t arrived[kPngXcds][16];  // the per-XCD barrier: workgroups that have arrived, counted up for ever (one cache line each)
-    uint32_t blocks[kPngXcds];     // workgroups running on each XCD
-    uint32_t max_rows;
-    uint32_t arrived_all;          // the one grid-wide barrier behind the set-up
-    uint32_t pad[6];
-};
-
-__device__ __forceinline__ uint32_t png_xcc_id() {
-    uint32_t x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    return x & (kPngXcds - 1);
-}
-__device__ __forceinline__ uint32_t png_load_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// 16 bytes that another CU of this XCD may have written in the row index before: past the L1
-__device__ __forceinline__ uint4 png_load16_sc1(const uint8_t* p) {
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-    const u32_unaligned* q = reinterpret_cast<const u32_unaligned*>(p);
-    uint4 v;
-    v.x = __hip_atomic_load(reinterpret_cast<const uint32_t*>(q + 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v.y = __hip_atomic_load(reinterpret_cast<const uint32_t*>(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v.z = __hip_atomic_load(reinterpret_cast<const uint32_t*>(q + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v.w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(q + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
-}
-__device__ __forceinline__ uint4 png_load_part_sc1(const uint8_t* p, uint32_t valid) {
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t k = 0; k < valid; k++) w[k >> 2] |= (uint32_t)__hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << (8 * (k & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// Barrier of the workgroups of a cooperative launch that count on `arrived` (every workgroup is resident: the
-// launch guarantees it).  FULL: grid-wide with release / acquire (the set-up: once); otherwise the workgroups
-// of one XCD, whose stores meet in that XCD's L2.
-template <bool FULL>
-__device__ __forceinline__ void png_barrier(uint32_t* arrived, const uint32_t target) {
-    if (FULL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (FULL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    else asm volatile("" ::: "memory");
-}
-
-template <int BPP, int TYPE>
-__device__ __forceinline__ uint4 png_chunk_typed(const uint4& f, const uint4& u, uint32_t (&la)[8], uint32_t (&ua)[8]) {
-    if (TYPE == 0) return f;
-    if (TYPE == 2) {  // Up: bytes add independently (SWAR: low seven bits, then the top bits)
-        auto add4 = [](uint32_t x, uint32_t y) { return ((x & 0x7F7F7F7Fu) + (y & 0x7F7F7F7Fu)) ^ ((x ^ y) & 0x80808080u); };
-        return make_uint4(add4(f.x, u.x), add4(f.y, u.y), add4(f.z, u.z), add4(f.w, u.w));
-    }
-    uint32_t o[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t a = k >= BPP ? o[k - BPP] : la[8 - BPP + k];
-        const uint32_t fv = png_byte(f, k);
-        uint32_t pr;
-        if (TYPE == 1) {
-            pr = a;
-        } else {
-            const uint32_t b = png_byte(u, k);
-            if (TYPE == 3) {
-                pr = (a + b) >> 1;
-            } else {
-                const uint32_t c = k >= BPP ? png_byte(u, k - BPP) : ua[8 - BPP + k];
-                pr = png_paeth(a, b, c);
-            }
-        }
-        o[k] = (fv + pr) & 0xFF;
-    }
-#pragma unroll
-    for (int k = 0; k < BPP; k++) {
-        la[8 - BPP + k] = o[16 - BPP + k];
-        if (TYPE == 4) ua[8 - BPP + k] = png_byte(u, 16 - BPP + k);
-    }
-    uint4 r;
-    r.x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-    r.y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
-    r.z = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
-    r.w = o[12] | (o[13] << 8) | (o[14] << 16) | (o[15] << 24);
-    return r;
-}
-
-// One row by one lane, 128 bytes (a cache line's worth per lane: eight back-to-back loads / stores) at a time,
-// the next piece requested while this one is computed.  `up`: the row above in the OUTPUT (HAS_UP: there is one).
-// Every lane has a row (the caller hands idle lanes a copy of a neighbour's: the same bytes written twice), and
-// the loads of the full pieces sit in no branch: behind a load in a branch the compiler waits for everything in
-// flight at the join, which would put a trip to memory into every 16 bytes.
-template <int BPP, int TYPE, bool HAS_UP>
-__device__ __forceinline__ void png_row_typed(const uint8_t* in, const uint8_t* in_end, const uint8_t* up, uint8_t* out, const uint32_t rb) {
-    constexpr bool kNeedUp = TYPE >= 2 && HAS_UP;
-    uint32_t la[8], ua[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) la[k] = ua[k] = 0;
-    const uint32_t nfull = rb >> 7;
-    if (nfull) {
-        uint4 nf[8], nu[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            nf[k] = png_load16(in + k * 16);
-            nu[k] = kNeedUp ? png_load16_sc1(up + k * 16) : make_uint4(0, 0, 0, 0);
-        }
-        for (uint32_t seg = 0; seg < nfull; seg++) {
-            uint4 f[8], u[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                f[k] = nf[k];
-                u[k] = nu[k];
-            }
-            const uint32_t nx = min(seg + 1, nfull - 1) * 128;  // (the last piece once more instead of a branch)
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                nf[k] = png_load16(in + nx + k * 16);
-                if (kNeedUp) nu[k] = png_load16_sc1(up + nx + k * 16);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) png_store16(out + seg * 128 + k * 16, png_chunk_typed<BPP, TYPE>(f[k], u[k], la, ua));
-        }
-    }
-    // the last piece of the row, chunk by chunk, never reading or writing behind it
-    for (uint32_t o = nfull * 128; o < rb; o += 16) {
-        const uint32_t valid = min(16u, rb - o);
-        const uint4 f = (in + o + 16 <= in_end) ? png_load16(in + o) : png_load_part(in + o, valid);
-        uint4 u = make_uint4(0, 0, 0, 0);
-        if (kNeedUp) u = valid == 16 ? png_load16_sc1(up + o) : png_load_part_sc1(up + o, valid);
-        png_store_part(out + o, png_chunk_typed<BPP, TYPE>(f, u, la, ua), valid);
-    }
-}
-
-template <int BPP>
-__global__ __launch_bounds__(kWave) void png_sorted_kernel(PngArgs a, uint32_t* work_raw) {
-    PngSortedWork* const W = reinterpret_cast<PngSortedWork*>(work_raw);
-    uint32_t* const order = work_raw + sizeof(PngSortedWork) / 4;  // order[((xcd * 2 + buf) * 5 + type) * cap + k]: image ids
-    const uint32_t lane = threadIdx.x;
-    const uint64_t n = a.n;
-    const uint64_t cap = png_sorted_cap(n);
-    const uint32_t rb = a.row_bytes;
-    const uint64_t src_row = (uint64_t)rb + 1;
-    const uint32_t me = png_xcc_id();
-    // appends image `i` (of the lanes with `want`) to the list of type `t` of XCD `x`, buffer `buf`, counter set `set`
-    auto append = [&](const bool want, const uint32_t t, const uint32_t i, const uint32_t x, const uint32_t buf, const uint32_t set) __attribute__((always_inline)) {
-#pragma unroll
-        for (uint32_t ty = 0; ty < 5; ty++) {
-            const uint64_t m = __ballot(want && t == ty);
-            if (m) {
-                const int first = __ffsll((unsigned long long)m) - 1;
-                uint32_t base = 0;
-                if ((int)lane == first) base = __hip_atomic_fetch_add(&W->ctr[x][set][ty], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                base = __shfl(base, first, kWave);
-                if (want && t == ty) order[(((uint64_t)x * 2 + buf) * 5 + ty) * cap + base + (uint32_t)__popcll(m & lanemask_lt((int)lane))] = i;
-            }
-        }
-    };
-    // ---- who is where: the XCDs that got workgroups of this launch (all eight unless the batch is tiny) ----
-    if (lane == 0) __hip_atomic_fetch_add(&W->blocks[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    png_barrier<true>(&W->arrived_all, gridDim.x);
-    uint32_t npop = 0, popmask = 0;
-#pragma unroll
-    for (uint32_t x = 0; x < kPngXcds; x++) {
-        if (png_load_sc1(&W->blocks[x]) != 0) {
-            popmask |= 1u << x;
-            npop++;
-        }
-    }
-    // the k-th populated XCD (k < npop)
-    auto nth_xcd = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {
-        uint32_t m = popmask;
-        for (uint32_t q = 0; q < k; q++) m &= m - 1;
-        return (uint32_t)__builtin_ctz(m);
-    };
-    // ---- the images: sizes, the decoder's verdict, the type of row 0; groups of 64 images go round those XCDs ----
-    for (uint64_t i0 = (uint64_t)blockIdx.x * kWave; i0 < n; i0 += (uint64_t)gridDim.x * kWave) {
-        const uint64_t i = i0 + lane;
-        bool want = false;
-        uint32_t t = 0;
-        if (i < n) {
-            uint32_t st = png_gate(a, i);
-            const uint64_t s0 = a.src_off[i], s1 = a.src_off[i + 1], d0 = a.dst_off[i], d1 = a.dst_off[i + 1];
-            const uint64_t rows = (s1 - s0) / src_row;
-            if (st == 0 && (rows * src_row != s1 - s0 || rows * rb > d1 - d0)) st = 2;
-            if (st == 0 && rows != 0) {
-                t = a.src[s0];
-                if (t > 4) st = 1;
-                else want = true;
-                atomicMax(&W->max_rows, (uint32_t)min(rows, (uint64_t)0xFFFFFFFFu));
-            }
-            a.status[i] = st;
-        }
-        append(want, t, (uint32_t)i, nth_xcd((uint32_t)((i0 / kWave) % npop)), 0, 0);
-    }
-    png_barrier<true>(&W->arrived_all, 2 * gridDim.x);
-    const uint32_t R = png_load_sc1(&W->max_rows);
-    const uint32_t mates = png_load_sc1(&W->blocks[me]);  // workgroups on this XCD
-    // this workgroup's place among them: the order of arrival at a counter (any order will do)
-    uint32_t rank = 0;
-    if (lane == 0) rank = __hip_atomic_fetch_add(&W->arrived[me][8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    rank = __shfl(rank, 0, kWave);
-    uint32_t round = 0;
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t set = r % 3, nxt = (r + 1) % 3, zero = (r + 2) % 3, buf = r & 1;
-        if (rank == 0 && lane < 5) __hip_atomic_store(&W->ctr[me][zero][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nobody looks at that set during this row index)
-        // the five lists back to back, 64 rows to a wavefront: a wavefront that straddles the end of a list works on
-        // two types (one after the other, under the execution mask), all the others on one
-        uint32_t cnt[5], lbase[6];
-        lbase[0] = 0;
-#pragma unroll
-        for (int ty = 0; ty < 5; ty++) {
-            cnt[ty] = png_load_sc1(&W->ctr[me][set][ty]);
-            lbase[ty + 1] = lbase[ty] + cnt[ty];
-        }
-        const uint32_t total = lbase[5], units = (total + kWave - 1) / kWave;
-        for (uint32_t uidx = rank; uidx < units; uidx += mates) {
-            const uint32_t g0 = uidx * kWave + lane;
-            const bool have = g0 < total;
-            const uint32_t g = min(g0, total - 1);  // (idle lanes shadow the last row: no branches around the row's loads)
-            uint32_t ty = 0;
-#pragma unroll
-            for (int q = 1; q < 5; q++) ty += g >= lbase[q] ? 1u : 0u;
-            const uint32_t lb = ty == 0 ? lbase[0] : ty == 1 ? lbase[1] : ty == 2 ? lbase[2] : ty == 3 ? lbase[3] : lbase[4];
-            const uint32_t i = png_load_sc1(&order[(((uint64_t)me * 2 + buf) * 5 + ty) * cap + (g - lb)]);
-            const uint64_t s0 = a.src_off[i], s1 = a.src_off[i + 1], d0 = a.dst_off[i];
-            const uint8_t* const in = a.src + s0 + (uint64_t)r * src_row + 1;
-            const uint8_t* const in_end = a.src + s1;
-            uint8_t* const out = a.dst + d0 + (uint64_t)r * rb;
-            const uint8_t* const up = out - rb;
-            if (r == 0) {  // (r is uniform; the type is, too, except in a wavefront that straddles two lists)
-                switch (ty) {
-                    case 0: png_row_typed<BPP, 0, false>(in, in_end, up, out, rb); break;
-                    case 1: png_row_typed<BPP, 1, false>(in, in_end, up, out, rb); break;
-                    case 2: png_row_typed<BPP, 2, false>(in, in_end, up, out, rb); break;
-                    case 3: png_row_typed<BPP, 3, false>(in, in_end, up, out, rb); break;
-                    default: png_row_typed<BPP, 4, false>(in, in_end, up, out, rb); break;
-                }
-            } else {
-                switch (ty) {
-                    case 0: png_row_typed<BPP, 0, true>(in, in_end, up, out, rb); break;
-                    case 1: png_row_typed<BPP, 1, true>(in, in_end, up, out, rb); break;
-                    case 2: png_row_typed<BPP, 2, true>(in, in_end, up, out, rb); break;
-                    case 3: png_row_typed<BPP, 3, true>(in, in_end, up, out, rb); break;
-                    default: png_row_typed<BPP, 4, true>(in, in_end, up, out, rb); break;
-                }
-            }
-            // the image's next row: its type decides which list the image goes to (a bad type ends the image)
-            const uint64_t rows = (s1 - s0) / src_row;
-            bool want = false;
-            uint32_t t = 0;
-            if (have && (uint64_t)r + 1 < rows) {
-                t = in[rb];
-                if (t > 4) a.status[i] = 1;
-                else want = true;
-            }
-            append(want, t, i, me, buf ^ 1u, nxt);
-        }
-        round++;
-        png_barrier<false>(&W->arrived[me][0], round * mates);
-    }
-}
-
 }  // namespace fdh
 
 // One image per wavefront by default; FDH_PNG_LANE_PER_IMAGE=1 selects the one-image-per-lane
 // kernel (of use only for batches of very many images of a few rows each).
-// The cooperative launch of png_sorted_kernel: as many one-wavefront workgroups as are resident at once.
-static int png_launch_sorted(const fdh::PngArgs& a_in, uint32_t bpp, hipStream_t stream) {
-    fdh::PngArgs a = a_in;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -1;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return -1;
-    int coop = 0;
-    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return -1;
-    const void* fn = nullptr;
-    switch (bpp) {
-        case 1: fn = reinterpret_cast<const void*>(&fdh::png_sorted_kernel<1>); break;
-        case 2: fn = reinterpret_cast<const void*>(&fdh::png_sorted_kernel<2>); break;
-        case 3: fn = reinterpret_cast<const void*>(&fdh::png_sorted_kernel<3>); break;
-        case 4: fn = reinterpret_cast<const void*>(&fdh::png_sorted_kernel<4>); break;
-        case 6: fn = reinterpret_cast<const void*>(&fdh::png_sorted_kernel<6>); break;
-        case 8: fn = reinterpret_cast<const void*>(&fdh::png_sorted_kernel<8>); break;
-        default: return -1;
-    }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, fdh::kWave, 0) != hipSuccess || per_cu <= 0) return -1;
-    const uint64_t want = (a.n + fdh::kWave - 1) / fdh::kWave;  // a unit per wavefront and row index at most
-    const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)per_cu * cus, std::max<uint64_t>(want, 1));
-    const size_t cap = (size_t)fdh::png_sorted_cap(a.n);
-    const size_t bytes = sizeof(fdh::PngSortedWork) + (size_t)fdh::kPngXcds * 10 * cap * sizeof(uint32_t);
-    uint32_t* work = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&work), bytes, stream) != hipSuccess) return -1;
-    if (hipMemsetAsync(work, 0, sizeof(fdh::PngSortedWork), stream) != hipSuccess) {
-        (void)hipFreeAsync(work, stream);
-        return -1;
-    }
-    void* args[] = {&a, &work};
-    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(fdh::kWave), args, 0, stream);
-    (void)hipFreeAsync(work, stream);
-    return e == hipSuccess ? 0 : -1;
-}
-
 template <bool UNFILTER>
 static int png_launch(const fdh::PngArgs& a, uint32_t bpp, hipStream_t stream) {
     if (a.n == 0) return 0;
@@ -875,16 +544,6 @@ static int png_launch(const fdh::PngArgs& a, uint32_t bpp, hipStream_t stream) {
     if (const char* e3 = getenv("FDH_PNG_IMAGES_PER_WAVE")) {  // (tests: the multi-image pipeline on small batches)
         const int v = atoi(e3);
         if (v >= 1 && v <= (int)fdh::kPipeMaxImages) per_wave = (uint32_t)v;
-    }
-    // FDH_PNG_SORTED=1: rows of one filter type per wavefront (png_sorted_kernel), one cooperative launch.
-    if (UNFILTER && !per_lane) {
-        const char* e4 = getenv("FDH_PNG_SORTED");
-        const bool sorted = e4 && e4[0] == '1';  // (an experiment: see png_sorted_kernel -- slower than the pipeline as it stands)
-        if (sorted) {
-            const int rc = png_launch_sorted(a, bpp, stream);
-            if (rc == 0) return 0;
-            (void)hipGetLastError();  // no cooperative launch here: the pipeline below
-        }
     }
     const size_t rowbuf_bytes = (size_t)((a.row_bytes + 15) / 16) * 16;
     const dim3 block(fdh::kWave);

@@ -98,7 +98,10 @@ enum {
  *                      `Decompressor::read` had produced when the input ran out (they are in the
  *                      slot); unspecified for other errors
  *   status[n]          per-stream status (above)
- *   adler[n]           Adler-32 of the decoded bytes (nullable)
+ *   adler[n]           Adler-32 of the decoded bytes (nullable): of all out_len[i] bytes for FDH_OK,
+ *                      FDH_WRONG_CHECKSUM and FDH_OUTPUT_TOO_LARGE; for any other status the value is that of a
+ *                      prefix of them and not specified further (a decoder that takes back the first literal of a
+ *                      cut-off pair -- src/decompress.rs:852 -- keeps the sum it had reached)
  *   flags              FDH_FLAG_*
  * All pointers are device pointers.  Truncated input reports FDH_INSUFFICIENT_INPUT exactly as
  * the one-shot wrapper does (src/decompress.rs:1135-1136); bytes after the Adler-32 trailer are
@@ -122,8 +125,9 @@ int fdh_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
  *               byte).  The stream's input must start with the same bytes as in the call that produced the
  *               record (more may have arrived behind them), and its output slot must start at the same
  *               place in the caller's data: it holds the `out_bytes` decoded so far (the LZ77 history) and
- *               may have grown.  With that flag only the tile / serial decoders run (the segment-parallel
- *               kernels start at a stream's first byte).
+ *               may have grown.  With that flag the LZ-window kernel goes on from the record and the
+ *               12-bit tile / serial decoders do the rest (the segment-parallel kernels for ultra-fast
+ *               streams start at a stream's first byte and do not run).
  * Status, length and Adler-32 of a stream that was stopped and taken up again -- any number of times, at any
  * split of input and output -- equal those of one fdh_inflate_batch call on the whole of it.
  */

@@ -89,6 +89,22 @@ extern "C" {
     pub fn fdh_shutdown() -> c_int;
     pub fn fdh_multi_device_count() -> c_int;
     pub fn fdh_inflate_batch_multi(shards: *const fdh_shard_t, n_shards: u32, flags: u32, meta_stride: u64) -> c_int;
+    pub fn fdh_multi_uses_rccl() -> c_int;
+
+    // the steps either side of the codec in the PNG pipeline (README.md:11 of the reference): scanline filters
+    pub fn fdh_png_unfilter_batch(filt: *const u8, filt_off: *const u64, pix: *mut u8, pix_off: *const u64,
+                                  png_status: *mut u32, n: u64, row_bytes: u32, bpp: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn fdh_png_filter_batch(pix: *const u8, pix_off: *const u64, types: *const u8, types_off: *const u64,
+                                filt: *mut u8, filt_off: *const u64, png_status: *mut u32, n: u64, row_bytes: u32,
+                                bpp: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn fdh_png_filter_deflate_ultrafast_batch(pix: *const u8, pix_off: *const u64, types: *const u8,
+                                                  types_off: *const u64, out: *mut u8, out_off: *const u64,
+                                                  out_len: *mut u32, png_status: *mut u32, n: u64, row_bytes: u32,
+                                                  bpp: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn fdh_inflate_png_batch(input: *const u8, in_off: *const u64, filt: *mut u8, filt_off: *const u64,
+                                 out_len: *mut u32, status: *mut u32, adler: *mut u32, pix: *mut u8,
+                                 pix_off: *const u64, png_status: *mut u32, n: u64, flags: u32, row_bytes: u32,
+                                 bpp: u32, hip_stream: *mut c_void) -> c_int;
 
     pub fn fdh_last_error() -> *const c_char;
     pub fn fdh_device_count() -> c_int;

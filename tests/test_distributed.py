@@ -117,3 +117,51 @@ def test_bench_launcher_starts_its_own_ranks_and_reports_failure():
     else:
         assert p.returncode != 0
         assert time.time() - t0 < 280
+
+
+@pytest.mark.gpu
+def test_one_rank_nccl_group_gathers_on_the_gpu():
+    """The branch `bench.py --gpus N` takes (torch.distributed backend "nccl" = RCCL, all_gather_into_tensor) with
+    one rank, in this process: shard, decode on the GPU through the C ABI, gather the per-stream results and a
+    payload with fdist.gather_metadata / gather_payload, compare with the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fdeflate_amd as fd
+    import oracle_binding as ob
+    from fdeflate_amd import distributed as fdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        n = 16
+        raws, comps = _make_batch(n)
+        lo, hi = fdist.shard_range(n, 0, 1)
+        assert (lo, hi) == (0, n)
+        blob = b"".join(comps)
+        in_off = np.zeros(n + 1, dtype=np.int64)
+        in_off[1:] = np.cumsum([len(c) for c in comps])
+        out_off = np.arange(n + 1, dtype=np.int64) * 2048
+        d_in = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+        d_out = torch.zeros(n * 2048, dtype=torch.uint8, device=dev)
+        out_len, status, adler = fd.inflate_batch(d_in, torch.from_numpy(in_off).to(dev), d_out, torch.from_numpy(out_off).to(dev))
+        meta = fdist.gather_metadata(status, out_len, adler)
+        full = fdist.gather_payload(d_out)
+        torch.cuda.synchronize()
+        assert meta.is_cuda and tuple(meta.shape) == (1, 3, n) and tuple(full.shape) == (1, n * 2048)
+        meta = meta.cpu().numpy()
+        h = full.cpu().numpy()[0]
+        for i in range(n):
+            st, out, ad = ob.decompress_bounded(comps[i], 2048)
+            assert int(meta[0, 0, i]) == st
+            if st in (0, 17):
+                assert int(meta[0, 1, i]) == len(out)
+            if st == 0:
+                assert int(np.uint32(np.int32(meta[0, 2, i]))) == ad
+                assert h[2048 * i:2048 * i + len(out)].tobytes() == out
+    finally:
+        dist.destroy_process_group()

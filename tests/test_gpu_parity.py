@@ -1123,14 +1123,6 @@ def test_png_filters_bit_exact_and_fused_decode(harness):
 
 
 @pytest.mark.gpu
-def test_png_rows_sorted_by_type_experiment(harness, monkeypatch):
-    """FDH_PNG_SORTED=1: the reconstruction kernel that takes the rows index by index, sorted by filter type,
-    in one cooperative launch (png_sorted_kernel: an experiment that is bit-exact but slower than the default
-    pipeline) -- the same checks as the default path."""
-    monkeypatch.setenv("FDH_PNG_SORTED", "1")
-    test_png_filters_bit_exact_and_fused_decode(harness)
-
-
 def test_png_filter_fused_into_the_ultrafast_encoder():
     """fdh_png_filter_deflate_ultrafast_batch: pixel rows in, the zlib stream of the filtered image
     out, bit for bit what the oracle's filter followed by the oracle's ultra-fast encoder gives --

@@ -46,7 +46,7 @@ def _streams():
     return out
 
 
-def _drive(fd, comps, in_cuts, out_cuts):
+def _drive(fd, comps, in_cuts, out_cuts, per_call=False):
     """All streams side by side in one batch; call k sees input up to in_cuts[i][k] and room up to out_cuts[i][k].
     A slot is [out_off[j], out_off[j + 1]): the room a stream does not have yet is the slot of an empty stream
     behind it (2n streams per call, every other one of length zero: InsufficientInput, nothing written).  The
@@ -84,6 +84,27 @@ def _drive(fd, comps, in_cuts, out_cuts):
         resume = r2[0::2].contiguous()
         res = (ln.cpu().numpy().view(np.uint32)[0::2].copy(), st.cpu().numpy().view(np.uint32)[0::2].copy(),
                ad.cpu().numpy().view(np.uint32)[0::2].copy())
+        if per_call:
+            # every call on its own: status, length and bytes so far are those of the reference's streaming `read`
+            # given the same input prefix and the same room in one go (src/decompress.rs:158-219 through the
+            # one-shot classification of :1111-1144), and a record is left exactly where the stream can go on
+            hk = d_out.cpu().numpy()
+            rk = resume.cpu().numpy()
+            for i in range(n):
+                cut = in_cuts[i][min(k, len(in_cuts[i]) - 1)]
+                room = out_cuts[i][min(k, len(out_cuts[i]) - 1)]
+                est, eout, _ = ob.decompress_bounded(comps[i][:cut], room)
+                assert int(res[1][i]) == est, (k, i, int(res[1][i]), est)
+                if est in (0, 17):
+                    assert int(res[0][i]) == len(eout) and hk[out_base[i]:out_base[i] + len(eout)].tobytes() == eout, (k, i)
+                if est == 2:
+                    d = ob.Decompressor()
+                    buf = np.zeros(max(room, 1), dtype=np.uint8)
+                    _, _, produced = d.read(comps[i][:cut], buf[:room], 0)
+                    assert int(res[0][i]) == produced, (k, i, int(res[0][i]), produced)
+                    assert hk[out_base[i]:out_base[i] + produced].tobytes() == buf[:produced].tobytes(), (k, i)
+                if est not in (2, 17):
+                    assert not rk[i].any(), (k, i, est, rk[i])  # "all zero for every other status"
     h = d_out.cpu().numpy()
     outs = [h[out_base[i]:out_base[i] + cap[i]] for i in range(n)]
     guards = all((h[out_base[i] + cap[i]:out_base[i + 1]] == 0xA5).all() for i in range(n))
@@ -121,7 +142,7 @@ def test_input_in_pieces(fd):
                 cuts = [len(c) - 9, len(c) - 5, len(c) - 4, len(c) - 1, len(c)]
             in_cuts.append(cuts)
         out_cuts = [[cap] for cap in caps]
-        res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts)
+        res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts, per_call=True)
         assert guards
         _check_final(names, comps, caps, res, outs)
 
@@ -136,7 +157,7 @@ def test_output_room_in_pieces(fd):
         caps = [len(x[2]) + final_slack for x in items]
         in_cuts = [[len(c)] for c in comps]
         out_cuts = [sorted(rnd.randrange(1, cap) for _ in range(5)) + [cap] for cap in caps]
-        res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts)
+        res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts, per_call=True)
         assert guards
         _check_final(names, comps, caps, res, outs)
 
@@ -151,7 +172,7 @@ def test_both_in_pieces_and_the_work_done(fd):
     steps = 8
     in_cuts = [[max(1, (len(c) * (k + 1)) // steps) for k in range(steps)] for c in comps]
     out_cuts = [[max(1, (cap * (k + 2)) // steps) if k + 2 < steps else cap for k in range(steps)] for cap in caps]
-    res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts)
+    res, outs, guards, _ = _drive(fd, comps, in_cuts, out_cuts, per_call=True)
     assert guards
     _check_final(names, comps, caps, res, outs)
     # the resume points after half of the steps lie well inside the streams
