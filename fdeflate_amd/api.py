@@ -38,6 +38,7 @@ FLAG_NO_INTERVALS = 0x400   # tests / A-B: skip the interval kernel (inflate_seg
 FLAG_INTERVALS_ONLY = 0x800  # debug: run only the interval kernel (what it leaves stays PENDING)
 FLAG_NO_LANDING = 0x10000    # tests / A-B: skip the landing decoder (inflate_seg3.h)
 FLAG_LANDING_ONLY = 0x20000  # debug: run only the landing decoder (what it leaves stays PENDING)
+FLAG_NO_OVERLAP = 0x100000   # tests / A-B: the LZ-window kernel behind the canonical kernels, not beside them
 FLAG_NO_LEAN_WRITE = 0x80000  # tests / A-B: the landing decoder always takes the interval decoder's general writing pass
 
 

@@ -934,6 +934,7 @@ extern "C" int fdh_debug_s2time(uint32_t* host) {
 static fdh::CanonTables* g_canon_dev[64] = {};
 static uint32_t* g_span_pool[64] = {};  // per device: scratch of the span decoder (never freed)
 static int g_cu_count[64] = {};         // per device: compute units (0 = not asked yet)
+static hipStream_t g_side_stream[64] = {};  // per device: the stream the LZ-window kernel runs on beside the canonical kernels
 static std::mutex g_dev_mutex;          // guards the three per-device caches above
 
 extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status) {
@@ -1065,6 +1066,20 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             cus = g_cu_count[ordinal & 63];
         }
         const bool seg2 = !(flags & 0x400u);
+        // A large batch is split by stream_order_kernel into the streams with the ultra-fast prefix and the others:
+        // two independent lists.  The LZ-window kernel takes the others on a stream of its own, beside the landing /
+        // interval / segment / tile kernels of the canonical ones, and the two meet again in front of the kernels
+        // that take what is left (round 4 ran the lists back to back: the mix of BASELINE config 5 paid the sum).
+        hipStream_t side = nullptr;
+        if (seg2 && !(flags & (0x1000u | 0x2000u | 0x800u | 0x20000u | 64u | 0x100000u))) {
+            std::lock_guard<std::mutex> lock(g_dev_mutex);
+            if (!g_side_stream[ordinal & 63]) {
+                hipStream_t s2 = nullptr;
+                if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess) g_side_stream[ordinal & 63] = s2;
+                else (void)hipGetLastError();
+            }
+            side = g_side_stream[ordinal & 63];
+        }
         const bool seg3 = seg2 && !(flags & 0x10000u);  // the landing decoder in front of the interval decoder
         const unsigned s2blocks = std::min((unsigned)((n + fdh::kS2Waves - 1) / fdh::kS2Waves), (unsigned)cus);
         // (+ the hand-out order of the interval kernel when every wavefront gets several streams);
@@ -1072,7 +1087,10 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         const bool ordered = seg2 && n >= 4ull * s2blocks * fdh::kS2Waves && n <= 0x7FFFFFFFull;
         const size_t list2_at = (size_t)(n + 4) + 4;
         const size_t list3_at = list2_at + (size_t)(n + 4) + (ordered ? (size_t)(2 * n) : 0);
-        const size_t list_words = list3_at + (seg3 ? (size_t)(n + 4) : 0);
+        const bool overlap = ordered && side != nullptr;
+        const size_t list4_at = list3_at + (seg3 ? (size_t)(n + 4) : 0);  // (overlap: what the canonical kernels leave)
+        const size_t list5_at = list4_at + (overlap ? (size_t)(n + 4) : 0);  // (overlap: what the LZ-window kernel leaves)
+        const size_t list_words = list5_at + (overlap ? (size_t)(n + 4) : 0);
         const size_t ckpt_bytes = seg2 ? (size_t)s2blocks * fdh::kS2Waves * fdh::kS2CkptPerWave * sizeof(uint2) : 0;
         const unsigned lblocks = (unsigned)std::min<uint64_t>(n, (uint64_t)FDH_LZ_WAVES_PER_CU * cus);  // LZ-window kernel: persistent wavefronts
         const size_t lzck_bytes = (flags & 0x1000u) ? 0 : (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
@@ -1085,7 +1103,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             // the headers of the lists and the counters between them: one fill over the list words is cheaper than three
             // small ones (a fill is a kernel of its own on the stream)
             if (seg3 || ordered) {
-                e = hipMemsetAsync(list, 0, list_words * sizeof(uint32_t), stream);
+                e = hipMemsetAsync(list, 0, words_al * sizeof(uint32_t), stream);
             } else {
                 e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
                 if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 8 * sizeof(uint32_t), stream);  // counters + second header
@@ -1114,10 +1132,41 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 sa.order = order;
                 sa.order_counts = counters;
             }
+            hipEvent_t ev_join = nullptr;
+            if (overlap) {  // the other list is complete: the LZ-window kernel starts on it now, on its own stream
+                hipEvent_t ev_fork = nullptr;
+                bool forked = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess &&
+                              hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess &&
+                              hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
+                if (forked) {
+                    fdh::InflateBatchArgs b = a;
+                    b.only_pending = 1;
+                    b.list = list + list2_at;
+                    b.list_out = list + list5_at;
+                    b.lz_counter = list + (n + 4) + 2;  // (a spare word of stream_order_kernel's counters, zeroed above)
+                    b.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes);
+                    b.resume = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes);
+                    hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, side, b);
+                    forked = hipGetLastError() == hipSuccess && hipEventRecord(ev_join, side) == hipSuccess;
+                }
+                if (ev_fork) (void)hipEventDestroy(ev_fork);
+                if (!forked) {  // (nothing has been started on the other stream, or it cannot be joined: give up cleanly)
+                    if (ev_join) (void)hipEventDestroy(ev_join);
+                    (void)hipStreamSynchronize(side);
+                    (void)hipFreeAsync(list, stream);
+                    return (int)hipErrorUnknown;
+                }
+                sa.list2 = nullptr;  // (nothing more goes on the other list: what the canonical kernels meet and cannot
+                                     //  take stays on their own lists)
+            }
             if (seg3) {  // what it does not take (short streams, a chain that did not land) is listed for the interval kernel
                 sa.list = list + list3_at;
                 e = (hipError_t)fdh_launch_seg3(sa, s2blocks, stream);
                 if (e != hipSuccess || (flags & 0x20000u)) {  // (debug: the landing decoder only)
+                    if (ev_join) {
+                        (void)hipStreamWaitEvent(stream, ev_join, 0);
+                        (void)hipEventDestroy(ev_join);
+                    }
                     (void)hipFreeAsync(list, stream);
                     return (int)e;
                 }
@@ -1127,16 +1176,54 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
             e = hipGetLastError();
             if (e != hipSuccess) {
+                if (ev_join) {
+                    (void)hipStreamWaitEvent(stream, ev_join, 0);
+                    (void)hipEventDestroy(ev_join);
+                }
                 (void)hipFreeAsync(list, stream);
                 return (int)e;
             }
             sa.src_list = list;
-            sa.list = list + list2_at;
+            sa.list = overlap ? list + list4_at : list + list2_at;
             sa.list2 = nullptr;
             sa.order = nullptr;
             if (flags & 0x800u) {  // debug: the interval kernel only
                 (void)hipFreeAsync(list, stream);
                 return 0;
+            }
+            if (overlap) {
+                // the segment kernel and the tile decoder on what the interval kernels left, then -- both lists done
+                // with their fast kernels -- the kernels that take whatever is still pending, list by list
+                const unsigned sblocks2 = std::min((unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves), (unsigned)(2 * cus));
+                hipLaunchKernelGGL(fdh::inflate_segments_kernel, dim3(sblocks2), dim3(fdh::kSegWaves * fdh::kWave), 0, stream, sa);
+                e = hipGetLastError();
+                a.only_pending = 1;
+                a.resume = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes);
+                a.list = list + list4_at;
+                if (e == hipSuccess) {
+                    const unsigned cblocks = (unsigned)((n + fdh::kCanonWaves - 1) / fdh::kCanonWaves);
+                    hipLaunchKernelGGL(fdh::inflate_canon_kernel, dim3(cblocks), dim3(fdh::kCanonWaves * fdh::kWave), 0, stream, a);
+                    e = hipGetLastError();
+                }
+                const hipError_t ej = hipStreamWaitEvent(stream, ev_join, 0);
+                (void)hipEventDestroy(ev_join);
+                if (e == hipSuccess) e = ej;
+                const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 4096);
+                for (int which = 0; which < 2 && e == hipSuccess; which++) {
+                    a.list = which == 0 ? list + list4_at : list + list5_at;
+                    if (!(flags & 0x200u)) {
+                        hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3(gblocks), dim3(fdh::kWave), 0, stream, a);
+                        e = hipGetLastError();
+                    }
+                    if (e == hipSuccess) {
+                        hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3(gblocks), dim3(fdh::kWave), 0, stream, a);
+                        e = hipGetLastError();
+                    }
+                }
+                a.list = nullptr;
+                if (e != hipSuccess) (void)hipStreamSynchronize(side);  // (the scratch is about to go)
+                (void)hipFreeAsync(list, stream);
+                return (int)e;
             }
         }
         unsigned sblocks = (unsigned)((n + fdh::kSegWaves - 1) / fdh::kSegWaves);

@@ -79,6 +79,7 @@ enum {
 #define FDH_FLAG_NO_LANDING     0x10000u /* tests/A-B: skip the landing decoder (the interval kernel counts for itself, as in rounds 3-4) */
 #define FDH_FLAG_LANDING_ONLY   0x20000u /* debug: run only the landing decoder (what it leaves stays PENDING) */
 #define FDH_FLAG_NO_LEAN_WRITE   0x80000u /* tests/A-B: the landing decoder always takes the interval decoder's general writing pass */
+#define FDH_FLAG_NO_OVERLAP      0x100000u /* tests/A-B: the LZ-window kernel runs behind the canonical kernels, not beside them */
 #define FDH_FLAG_LANDING_COUNT_ONLY 0x40000u /* debug: the landing decoder counts and leaves every stream PENDING */
 #define FDH_FLAG_SPANS          0x100u /* experimental: segment-parallel "span" decoder inside the 12-bit general kernel */
 
