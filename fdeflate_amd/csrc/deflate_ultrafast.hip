@@ -329,6 +329,9 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel_t(
     }
     if ((uint64_t)lane >= nchunks) x_next = 0;
     for (uint64_t t0 = 0; t0 < nchunks; t0 += kWave) {
+        // (the ring's counters are uniform; said so, their 64-bit arithmetic goes to the scalar unit)
+        enc.qbits = uni64(enc.qbits);
+        enc.qflushed = uni64(enc.qflushed);
         const uint64_t c = t0 + lane;
         const bool valid = c < nchunks;
         const uint64_t x = x_next;
@@ -357,19 +360,33 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel_t(
         const uint32_t lz_b = __shfl(lzb, b < 0 ? 0 : b, kWave);
         const uint32_t P = b >= 0 ? lz_b + 8u * (uint32_t)(lane - b - 1) : carry + 8u * (uint32_t)lane;
         const bool pend = nz && P > 0;
-        const uint32_t lo = pend ? tzb : 0, hi = 8 - lzb;
-        // ---- literals of bytes [lo, hi): four 2-byte pieces (<= 24 bits each) ----
+        const uint32_t lo = pend ? tzb : 0;  // (and the lzb high zero bytes start the next run)
+        // ---- literals of bytes [lo, hi): the codes of all eight bytes are looked up and packed without a
+        //      predicate per byte (round 5; rounds 1-4 spent five instructions per byte on `is byte j inside`):
+        //      the bytes outside are ZERO bytes, whose code is two zero bits (HUFFMAN_CODES[0] == 0, length 2,
+        //      ultrafast.rs:62), so dropping the low ones is a shift of the packed string by 2 x lo bits and
+        //      dropping the high ones shortens it by 2 bits each -- they are zeros either way ----
         uint32_t pb[4], pn[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t j0 = 2 * k, j1 = 2 * k + 1;
-            uint32_t e0 = lds.tab[(uint32_t)(x >> (8 * j0)) & 0xFF];
-            uint32_t e1 = lds.tab[(uint32_t)(x >> (8 * j1)) & 0xFF];
-            bool u0 = nz && j0 >= lo && j0 < hi, u1 = nz && j1 >= lo && j1 < hi;
-            uint32_t n0 = u0 ? e0 >> 16 : 0, n1 = u1 ? e1 >> 16 : 0;
-            uint32_t c0 = u0 ? e0 & 0xFFFF : 0, c1 = u1 ? e1 & 0xFFFF : 0;
-            pb[k] = c0 | (c1 << n0);
-            pn[k] = n0 + n1;
+            const uint32_t e0 = lds.tab[(uint32_t)(x >> (16 * k)) & 0xFF];
+            const uint32_t e1 = lds.tab[(uint32_t)(x >> (16 * k + 8)) & 0xFF];
+            const uint32_t n0 = e0 >> 16;
+            pb[k] = (e0 & 0xFFFF) | ((e1 & 0xFFFF) << n0);
+            pn[k] = n0 + (e1 >> 16);
+        }
+        const uint32_t drop_lo = 2 * lo, drop = drop_lo + 2 * lzb;
+        uint32_t lit_n = 0;       // bits of the chunk's literals
+        uint64_t l0 = 0, l1 = 0;  // ... and the bits themselves (<= 96)
+        {
+            const uint64_t la = (uint64_t)pb[0] | ((uint64_t)pb[1] << pn[0]);
+            const uint64_t lb = (uint64_t)pb[2] | ((uint64_t)pb[3] << pn[2]);
+            const uint32_t na = pn[0] + pn[1];  // <= 48, >= 4
+            const uint64_t f0 = la | (lb << na);
+            const uint64_t f1 = lb >> (64 - na);
+            l0 = drop_lo ? (f0 >> drop_lo) | (f1 << (64 - drop_lo)) : f0;
+            l1 = f1 >> drop_lo;
+            lit_n = nz ? na + pn[2] + pn[3] - drop : 0u;
         }
         // ---- run closed by this chunk (write_run, ultrafast.rs:45-67) ----
         uint32_t nrep = 0, tail_bits = 0, tail_n = 0, run_n = 0;
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel_t(
             run_n = 2 + nrep * ((lds.tab[285] >> 16) + 1) + tail_n;
         }
         const uint32_t e285 = lds.tab[285];
-        const uint32_t lane_bits = run_n + pn[0] + pn[1] + pn[2] + pn[3];
+        const uint32_t lane_bits = run_n + lit_n;
         uint32_t total;
         const uint32_t off = wave_excl_scan_u32(lane_bits, lane, total);
         if ((uint64_t)total + (enc.qbits - enc.qflushed) > kEncTileBudget) {
@@ -392,10 +409,14 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel_t(
                 bool p_l = __shfl((int)pend, l, kWave) != 0;
                 uint32_t P_l = __shfl(P, l, kWave), tz_l = __shfl(tzb, l, kWave);
                 if (p_l) enc.emit_run_uniform(P_l + tz_l);
+                uint32_t left = __shfl(lit_n, l, kWave);
+                const uint32_t w[3] = {(uint32_t)__shfl((int)(uint32_t)l0, l, kWave), (uint32_t)__shfl((int)(uint32_t)(l0 >> 32), l, kWave),
+                                       (uint32_t)__shfl((int)(uint32_t)l1, l, kWave)};
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t bits = __shfl(pb[k], l, kWave), nb = __shfl(pn[k], l, kWave);
-                    enc.emit_uniform(bits, nb);
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t nb = min(left, 32u);
+                    enc.emit_uniform(nb < 32 ? w[k] & ((1u << nb) - 1) : w[k], nb);
+                    left -= nb;
                 }
             }
         } else {
@@ -413,12 +434,7 @@ __global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel_t(
                 pre_bits = tail_bits;  // ... then the tail of the run in front of the chunk's literals
                 pre_n = tail_n;
             }
-            // ... and the chunk's literals, packed in registers: <= 22 + 96 bits
-            const uint64_t la = (uint64_t)pb[0] | ((uint64_t)pb[1] << pn[0]);
-            const uint64_t lb = (uint64_t)pb[2] | ((uint64_t)pb[3] << pn[2]);
-            const uint32_t na = pn[0] + pn[1];  // <= 48
-            const uint64_t l0 = la | (lb << na);
-            const uint64_t l1 = na ? lb >> (64 - na) : 0;
+            // ... and the chunk's literals: <= 22 + 96 bits
             const uint64_t v0 = (uint64_t)pre_bits | (l0 << pre_n);
             const uint64_t v1 = (l1 << pre_n) | (pre_n ? l0 >> (64 - pre_n) : 0);
             enc.or_bits128(pos, v0, v1);
