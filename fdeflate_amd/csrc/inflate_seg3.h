@@ -503,24 +503,40 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
     for (uint32_t x = 16 * (uint32_t)lane; x < kS2OutCap; x += 16 * kWave)
         *reinterpret_cast<uint4*>(imgB8 + x) = make_uint4(0, 0, 0, 0);
 
-    // The intervals of a round: interval f belongs to the last lane whose P <= f (binary search over the lanes' P
-    // by ds_bpermute); its two checkpoints are requested, what turns them into stream bits / output bytes is kept.
+    // The intervals of a round: interval f belongs to the last lane whose P <= f; its two checkpoints are requested,
+    // what turns them into stream bits / output bytes is kept.  The owners of 64 consecutive intervals are a handful
+    // of consecutive lanes, starting at the owner of the round's first interval -- known from the round before: the
+    // P of the next eight lanes is read into scalar registers and compared (no dependent trips to the LDS crossbar;
+    // rounds 3-4: a six-step binary search by ds_bpermute); only when a ninth owner could be among them (lanes with
+    // a single interval: tiny streams) the search runs.
     struct Fetch {
         uint2 e0, e1;
-        uint32_t pbase, qbase;
+        uint32_t pbase, qbase, sg;
         bool valid;
     };
-    auto fetch = [&](uint32_t fbase) __attribute__((always_inline)) {
+    auto fetch = [&](uint32_t fbase, uint32_t sg_first) __attribute__((always_inline)) {
         Fetch t;
         const uint32_t f = fbase + (uint32_t)lane;
         t.valid = f < ni;
-        uint32_t sg = 0;
+        uint32_t sg = sg_first;  // (uniform) owner of interval fbase, or a lane in front of it
+        bool beyond = false;
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-            const uint32_t probe = sg + step;
-            const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((probe & 63) << 2), (int)plan.P);
-            if (probe < (uint32_t)kWave && pv <= f) sg = probe;
+        for (uint32_t j = 1; j <= 9; j++) {
+            const uint32_t probe = sg_first + j;
+            const uint32_t pv = probe < (uint32_t)kWave ? (uint32_t)__builtin_amdgcn_readlane((int)plan.P, (int)(probe & 63)) : 0xFFFFFFFFu;
+            if (j <= 8) sg += pv <= f ? 1u : 0u;
+            else beyond = pv <= f;
         }
+        if (__any(beyond && t.valid)) {
+            sg = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const uint32_t probe = sg + step;
+                const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((probe & 63) << 2), (int)plan.P);
+                if (probe < (uint32_t)kWave && pv <= f) sg = probe;
+            }
+        }
+        t.sg = sg;
         const uint32_t sP = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.P);
         t.qbase = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sg << 2), (int)plan.obase);
         t.pbase = a.canon_bits + sg * seg;
@@ -542,7 +558,12 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         c1 = make_uint2(t.pbase + (t.e1.x & posmask), t.qbase + t.e1.y);
         valid = t.valid;
     };
-    settle(fetch(0));
+    uint32_t own = 0;  // per lane: the owner of this lane's interval of the current round
+    {
+        const Fetch t0 = fetch(0, 0);
+        settle(t0);
+        own = t0.sg;
+    }
     uint32_t n = 0, ib = 0;
     const uint8_t* a0 = in;
     auto stage_c = [&](uint32_t wq_) __attribute__((always_inline)) {
@@ -585,7 +606,7 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         const uint32_t in_off0 = (uint32_t)(a0 - in), ib_cur = ib;
         const uint32_t qf_new = __builtin_amdgcn_readlane(c1.y, (int)(n - 1));
         // ---- the next round's intervals are on their way while this one decodes ----
-        const Fetch nx = fetch(f0 + n);
+        const Fetch nx = fetch(f0 + n, (uint32_t)__builtin_amdgcn_readlane((int)own, (int)min(n, (uint32_t)kWave - 1)));
         S3W(0);
         // ---- the input image (requested a round ago; the flush's stores and the two loads above came later) ----
         s2_wait_vm(stores_behind + (f0 + n < ni ? 2u : 0u));
@@ -644,28 +665,37 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         const uint32_t xa_new = qa_new - wq, n_cur = n;
         // ---- the next round: its intervals, how many fit, its input bytes (this round is done with the image) ----
         settle(nx);
+        own = nx.sg;
         if (!final_round) {
             stage_c(qa_new - 16);
             request(a0);
         }
         stores_behind = final_round ? 64u : (xa_new - 16 + 1023) / 1024;
         S3W(4);
-        // ---- flush: whole 128-B lines of the image (everything once the stream ends), one store per KiB ----
-        for (uint32_t x = 16 + 16 * (uint32_t)lane; __any(x < xa_new); x += 16 * kWave) {
-            const uint32_t v = wq + x;
-            if (x < xa_new && v + 16 <= total) {
-                const uint4 q = *reinterpret_cast<const uint4*>(imgB8 + x);
-                *reinterpret_cast<uint4*>(op + v) = q;
-                uint32_t sum = bytesum4(q.x);
-                sum = __builtin_amdgcn_sad_u8(q.y, 0u, sum);
-                sum = __builtin_amdgcn_sad_u8(q.z, 0u, sum);
-                sum = __builtin_amdgcn_sad_u8(q.w, 0u, sum);
-                ad_u = bytedot4(q.x, 0x03020100u, ad_u);
-                ad_u = bytedot4(q.y, 0x07060504u, ad_u);
-                ad_u = bytedot4(q.z, 0x0b0a0908u, ad_u);
-                ad_u = bytedot4(q.w, 0x0f0e0d0cu, ad_u);
-                ad_a += sum;
-                ad_b += (unsigned long long)(total - v) * sum;
+        // ---- flush: whole 128-B lines of the image (everything once the stream ends), one store per KiB; two pieces
+        //      per trip, both read before the first is used ----
+        auto piece = [&](const uint4 q, const uint32_t v) __attribute__((always_inline)) {
+            *reinterpret_cast<uint4*>(op + v) = q;
+            uint32_t sum = bytesum4(q.x);
+            sum = __builtin_amdgcn_sad_u8(q.y, 0u, sum);
+            sum = __builtin_amdgcn_sad_u8(q.z, 0u, sum);
+            sum = __builtin_amdgcn_sad_u8(q.w, 0u, sum);
+            ad_u = bytedot4(q.x, 0x03020100u, ad_u);
+            ad_u = bytedot4(q.y, 0x07060504u, ad_u);
+            ad_u = bytedot4(q.z, 0x0b0a0908u, ad_u);
+            ad_u = bytedot4(q.w, 0x0f0e0d0cu, ad_u);
+            ad_a += sum;
+            ad_b += (unsigned long long)(total - v) * sum;
+        };
+        for (uint32_t x = 16 + 16 * (uint32_t)lane; __any(x < xa_new); x += 32 * kWave) {
+            const uint32_t x2 = x + 16 * kWave, v = wq + x, v2 = wq + x2;
+            const bool g1 = x < xa_new && v + 16 <= total, g2 = x2 < xa_new && v2 + 16 <= total;
+            uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1;
+            if (g1) q1 = *reinterpret_cast<const uint4*>(imgB8 + x);
+            if (g2) q2 = *reinterpret_cast<const uint4*>(imgB8 + x2);
+            if (g1) piece(q1, v);
+            if (__any(g2)) {
+                if (g2) piece(q2, v2);
             }
         }
         S3W(5);
