@@ -140,9 +140,45 @@ def test_valid_streams_every_decoder_variant(harness):
             blobs.append(comp)
             caps.append(c)
     # 256: span decoder (experimental); 0x400: without the interval kernel; 0x1000: without the LZ-window
-    # kernel (the tile decoders take the general streams, as before round 4)
-    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8, 256, 256 | 8, 256 | 4 | 8, 0x400, 0x400 | 8, 0x1000, 0x1000 | 8):
+    # kernel (the tile decoders take the general streams, as before round 4); round 5: 0x10000 without the
+    # landing decoder, 0x80000 the landing decoder with the general writing pass only, 0x100000 one stream
+    for flags in (8, 4 | 8, 2, 16, 16 | 8, 128, 128 | 8, 256, 256 | 8, 256 | 4 | 8, 0x400, 0x400 | 8, 0x1000, 0x1000 | 8,
+                  0x10000, 0x10000 | 8, 0x80000, 0x80000 | 8, 0x100000):
         harness.assert_inflate_parity(names, blobs, caps, flags=flags)
+
+
+def test_landing_decoder_alone(harness):
+    """inflate_seg3_kernel on its own (FDH_FLAG_LANDING_ONLY: what it leaves stays PENDING), with its lean
+    and with the general writing pass: every stream it reports is right -- status, length, bytes, Adler-32
+    against the oracle -- and it takes every ultra-fast stream (but the empty buffer's: shorter than the fixed
+    prefix + 44 bits, left to the interval kernel) of the bench's three kinds of buffers (noisy
+    rows, every other row zero, all zero), short ones and long ones, in exact and loose slots, at every
+    alignment of input and slot (the harness packs back to back with odd guard slots in between)."""
+    from fdeflate_amd import synth
+    names, blobs, caps = [], [], []
+    for sid, ln in ((0, 65536), (1, 65536), (7, 65536), (15, 65536), (3, 20000), (4, 300), (5, 0), (9, 200000), (23, 131072),
+                    (31, 70000), (2, 4096), (6, 9), (8, 1023), (10, 1024), (11, 1025)):
+        raw = synth.gen_stream_np(sid, ln).tobytes()
+        comp = ob.compress_ultra_fast(raw)
+        for c in (ln, ln + 17):
+            names.append("uf%d_%d@%d" % (sid, ln, c))
+            blobs.append(comp)
+            caps.append(c)
+    rs, rl, ra, ro = harness.oracle_inflate(blobs, caps)
+    for flags in (0x20000, 0x20000 | 0x80000):
+        st, ln_, ad, outs, guards_ok = harness.gpu_inflate(blobs, caps, flags=flags)
+        assert guards_ok
+        took = 0
+        for i, name in enumerate(names):
+            if st[i] == 0xFFFFFFFF:
+                # (the only streams it may pass on: shorter than the fixed prefix + 44 bits -- the empty buffer)
+                assert len(blobs[i]) * 8 < 429 + 44, (name, len(blobs[i]), flags)
+                took += 1
+                continue
+            took += 1
+            assert int(st[i]) == rs[i] == 0, (name, int(st[i]), rs[i], flags)
+            assert int(ln_[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], (name, flags)
+        assert took == len(names), (took, len(names), flags)
 
 
 
