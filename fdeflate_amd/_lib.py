@@ -93,6 +93,8 @@ def lib():
     L.fdh_decompressor_attempts.restype = C.c_uint64
     L.fdh_decompressor_decoded_bytes.argtypes = [vp]
     L.fdh_decompressor_decoded_bytes.restype = C.c_uint64
+    L.fdh_decompressor_device_bytes.argtypes = [vp]
+    L.fdh_decompressor_device_bytes.restype = C.c_uint64
     L.fdh_decompressor_read.restype = C.c_int
     L.fdh_decompressor_read.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]
     _lib = L
@@ -105,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "fdh_decompress_to_vec", "fdh_decompress_to_vec_bounded", "fdh_compress_to_vec_ultra_fast",
     "fdh_free", "fdh_stored_size", "fdh_deflate_stored_batch", "fdh_compress_to_vec_stored",
     "fdh_decompressor_new", "fdh_decompressor_free", "fdh_decompressor_ignore_adler32",
-    "fdh_decompressor_is_done", "fdh_decompressor_read", "fdh_decompressor_attempts", "fdh_decompressor_decoded_bytes",
+    "fdh_decompressor_is_done", "fdh_decompressor_read", "fdh_decompressor_attempts", "fdh_decompressor_decoded_bytes", "fdh_decompressor_device_bytes",
     "fdh_compress_bound", "fdh_deflate_general_batch", "fdh_compress_to_vec", "fdh_compress_to_vec_rle",
     "fdh_png_unfilter_batch", "fdh_png_filter_batch", "fdh_inflate_png_batch", "fdh_png_filter_deflate_ultrafast_batch",
     "fdh_init", "fdh_shutdown", "fdh_multi_device_count", "fdh_multi_uses_rccl", "fdh_inflate_batch_multi",

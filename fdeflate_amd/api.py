@@ -94,6 +94,10 @@ class Decompressor:
         """Output bytes decoded by all attempts together (introspection, fdh_decompressor_decoded_bytes)."""
         return int(self._L.fdh_decompressor_decoded_bytes(self._d))
 
+    def device_bytes(self):
+        """The most device memory the object's buffers have held together (introspection, fdh_decompressor_device_bytes)."""
+        return int(self._L.fdh_decompressor_device_bytes(self._d))
+
     def read(self, data, output, output_position):
         data = bytes(data)
         mv = memoryview(output)

@@ -110,3 +110,21 @@ extern "C" int fdh_launch_deflate_stored(const uint8_t* in, const uint64_t* in_o
     hipLaunchKernelGGL(fdh::deflate_stored_kernel, dim3(blocks), dim3(fdh::kStoWaves * fdh::kWave), 0, stream, a);
     return (int)hipGetLastError();
 }
+
+// ---- 16-byte lines from one place of device memory to another (stream_decompressor.cpp) ----
+// The streaming object moves what it keeps of a stream to the front of its buffers with this kernel (a few hundred KiB at
+// most, on the object's own stream, between two decode attempts).  src and dst 16-byte aligned, ranges must not overlap.
+namespace fdh {
+__global__ __launch_bounds__(256) void copy_lines_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t lines) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < lines; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace fdh
+
+extern "C" int fdh_launch_copy_lines(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    const size_t lines = (bytes + 15) / 16;
+    if (lines == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((lines + 255) / 256, 1024);
+    hipLaunchKernelGGL(fdh::copy_lines_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint4*>(dst), static_cast<const uint4*>(src), lines);
+    return (int)hipGetLastError();
+}
+

@@ -91,13 +91,20 @@ struct InflateBatchArgs {
     uint4* resume_out;     // nullable (fdh_inflate_batch_resumable): per stream, where a stream that ended InsufficientInput
                            // or OutputTooLarge can be taken up again (all zero: from its first byte); same layout
 };
+// Statuses and resume records are written by the kernel in front (or by an earlier kernel of the same call) and read
+// here with a wavefront-uniform index: plain device-scope loads, whatever the compiler would have picked.
+__device__ __forceinline__ uint32_t load_word(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint4 load_record(const uint4* p) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+    return make_uint4(load_word(w), load_word(w + 1), load_word(w + 2), load_word(w + 3));
+}
 // The resume point a kernel in front left for stream `sid`, whose status is `st` (if any).
 __device__ __forceinline__ ResumePoint resume_point(const InflateBatchArgs& a, const uint64_t sid, const uint32_t st) {
     ResumePoint rp;
     rp.valid = 0;
     rp.step = 0;
     if (a.resume && a.only_pending && (st == kPendingResume || st == kPendingSerial) && !(a.flags & 0x4000u)) {
-        const uint4 v = a.resume[sid];
+        const uint4 v = load_record(&a.resume[sid]);
         rp.hdr_bit = v.x & 0x3FFFFFFFu;
         rp.step = v.x >> 30;
         rp.bit = v.y;
@@ -158,7 +165,7 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
     bool tiles = !(a.flags & 2u);
     uint32_t st = kPending;
     if (a.only_pending) {
-        st = a.status[sid];
+        st = load_word(&a.status[sid]);
         if (st != kPending && st != kPendingSerial && st != kPendingResume) return;
     }
     const StreamArgs s = stream_args(a, sid);
@@ -166,6 +173,10 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
     StreamResult r;
     const ResumePoint rec = resume_point(a, sid, st);  // where a kernel in front left the stream
     ResumePoint rp = rec;
+#ifdef FDH_DEBUG_STEP
+    if (lane == 0) printf("general_one: sid %llu st %x tiles %d rec{valid %u h %llu b %llu o %u step %u} in_len %llu cap %u flags %x\n", (unsigned long long)sid, st, (int)tiles,
+                          rec.valid, (unsigned long long)rec.hdr_bit, (unsigned long long)rec.bit, rec.opos, rec.step, (unsigned long long)s.in_len, s.cap, a.flags);
+#endif
     // A tile decoder in front has been over this stream and left it for the exact serial decoder: no second
     // pass of tiles, with or without a check point to start from (without one -- no scratch for the records, or
     // FDH_FLAG_NO_CHECKPOINTS -- the serial decoder starts at the stream's first byte).
@@ -214,7 +225,7 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
         if (whole && (a.flags & 0x8000u) && a.resume_out && a.resume_out != a.resume) {
             // ... then from the point this CALL took the stream up at, if that one knows its place among the steps
             // (the caller's record is still there: a final result overwrites it, and there is none yet)
-            const uint4 v = a.resume_out[sid];
+            const uint4 v = load_record(&a.resume_out[sid]);
             ResumePoint first;
             first.hdr_bit = v.x & 0x3FFFFFFFu;
             first.step = v.x >> 30;
@@ -231,6 +242,10 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
         }
         if (whole) r = inf.run<false, false>();
     }
+#ifdef FDH_DEBUG_STEP
+    if (lane == 0) printf("general_one: sid %llu -> status %u len %u tiles %d rp{valid %u h %llu b %llu o %u} ck{valid %u h %llu b %llu o %u}\n", (unsigned long long)sid, r.status, r.out_len, (int)tiles,
+                          rp.valid, (unsigned long long)rp.hdr_bit, (unsigned long long)rp.bit, rp.opos, inf.ck.valid, (unsigned long long)inf.ck.hdr_bit, (unsigned long long)inf.ck.bit, inf.ck.opos);
+#endif
     if (lane == 0) {
         a.status[sid] = r.status;
         a.out_len[sid] = r.out_len;
@@ -284,7 +299,7 @@ __device__ __forceinline__ void general_fast_one(const InflateBatchArgs& a, Gene
     if (sid >= a.n) return;
     uint32_t st = kPending;
     if (a.only_pending) {
-        st = a.status[sid];
+        st = load_word(&a.status[sid]);
         if (st != kPending && st != kPendingResume) return;
     }
     const StreamArgs s = stream_args(a, sid);
@@ -329,7 +344,7 @@ __device__ __forceinline__ bool lz_one(const InflateBatchArgs& a, LzLds& L, cons
     if (sid >= a.n) return false;
     uint32_t st = kPending;
     if (a.only_pending) {  // finished by a kernel in front: nothing to do; left for the exact serial decoder: not ours
-        st = a.status[sid];
+        st = load_word(&a.status[sid]);
         if (st != kPending && st != kPendingResume) return st != kPendingSerial;
     }
     const StreamArgs s = stream_args(a, sid);
@@ -937,6 +952,40 @@ static int g_cu_count[64] = {};         // per device: compute units (0 = not as
 static hipStream_t g_side_stream[64] = {};  // per device: the stream the LZ-window kernel runs on beside the canonical kernels
 static std::mutex g_dev_mutex;          // guards the three per-device caches above
 
+// Scratch of a call (lists, check points, records): stream-ordered allocations from a pool of the library's own that
+// KEEPS what is freed (release threshold = everything).  With the device's default pool -- which hands its memory back
+// at every synchronisation -- a call that followed a hipStreamSynchronize got fresh pages, and about one such call in
+// ten then read ZEROS where the first kernel of the call had just written (seen on the record resume_prepare_kernel
+// leaves for the kernels behind it: status "taken up at a resume point", record all zero).  Until round 5 that only
+// cost time -- a stream without a record is decoded from its first byte -- and went unnoticed; with the streaming
+// object's moved buffers (stream_decompressor.cpp) it decoded garbage.  Memory that stays mapped does not do it
+// (tools/streamtime.py, 16 runs of ~130 calls each: 0 failures against 6 in 8), and a call no longer pays for mapping
+// and unmapping its scratch.
+static hipMemPool_t g_scratch_pool[64];
+static hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream) {
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        if (!g_scratch_pool[dev]) {
+            hipMemPoolProps props = {};
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            hipMemPool_t q = nullptr;
+            if (hipMemPoolCreate(&q, &props) == hipSuccess && q) {
+                uint64_t keep = ~0ull;
+                (void)hipMemPoolSetAttribute(q, hipMemPoolAttrReleaseThreshold, &keep);
+                g_scratch_pool[dev] = q;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        pool = g_scratch_pool[dev];
+    }
+    return pool ? hipMallocFromPoolAsync(p, bytes, pool, stream) : hipMallocAsync(p, bytes, stream);
+}
+
 extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status) {
     hipLaunchKernelGGL(fdh::canon_build_kernel, dim3(1), dim3(fdh::kWave), 0, stream);
     hipError_t e = hipGetLastError();
@@ -1000,7 +1049,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         const size_t list_words = ((size_t)n + 8 + 3) & ~(size_t)3;
         const size_t lzck_bytes = (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
         uint32_t* scratch = nullptr;
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), list_words * sizeof(uint32_t) + lzck_bytes + (size_t)n * sizeof(uint4), stream);
+        hipError_t e = scratch_alloc(reinterpret_cast<void**>(&scratch), list_words * sizeof(uint32_t) + lzck_bytes + (size_t)n * sizeof(uint4), stream);
         if (e != hipSuccess) return (int)e;
         a.lz_counter = scratch + 2;
         a.list = scratch + 4;   // [0] = count, [4..] = ids (its hand-out words [2], [3] are not used by this kernel)
@@ -1096,7 +1145,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         const size_t lzck_bytes = (flags & 0x1000u) ? 0 : (size_t)lblocks * fdh::kWave * fdh::kLzMaxPhases * sizeof(uint2);
         const size_t resume_bytes = (size_t)n * sizeof(uint4);  // where a kernel leaves a stream for the kernels behind it
         const size_t words_al = (list_words + 3) & ~(size_t)3;  // (what follows the lists is 16-byte aligned)
-        if (hipMallocAsync(reinterpret_cast<void**>(&list), words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes + resume_bytes, stream) != hipSuccess) {
+        if (scratch_alloc(reinterpret_cast<void**>(&list), words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes + resume_bytes, stream) != hipSuccess) {
             (void)hipGetLastError();
             list = nullptr;  // fall back to the status-scan form
         } else {

@@ -246,7 +246,7 @@ int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *fi
  * `read` writes only output[output_position .. output_position + *produced); bytes in front of
  * output_position are never read or written.  When it returns FDH_SUCCESS with *stream_status ==
  * FDH_STREAM_OK at least one of the reference's post-conditions holds (src/decompress.rs:167-170):
- * the input is fully consumed (always: *consumed == input_len), the output is full but there are
+ * the input is fully consumed (almost always: see 1. below), the output is full but there are
  * more bytes, or the stream is complete (is_done).  Once done, read returns (0, 0)
  * (src/decompress.rs:185-187).  A `DecompressionError` is reported in *stream_status (1 + ordinal)
  * and is sticky.  An EMPTY input asks for whatever can still be produced from the bytes already
@@ -256,15 +256,21 @@ int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *fi
  *
  * Where the (consumed, produced) pairs differ from the reference's -- the bytes delivered over a whole
  * stream, their order, the final status and is_done never do (tests/test_gpu_streaming.py):
- *   1. *consumed == input_len on EVERY call: the input is buffered on the device, whereas the reference
- *      stops consuming once the output is full (src/decompress.rs:167-170).  A caller written against
- *      the contract ("consumed bytes must not be offered again") behaves identically.
- *   2. With more than 256 KiB of buffered input a call with NON-EMPTY input may return (input_len, 0)
- *      without a decode attempt (attempts are then made when the stream has grown by 1/8 or by 256 KiB,
+ *   1. Input is buffered on the device, so a call usually consumes all of it where the reference stops once
+ *      the output is full (src/decompress.rs:167-170).  *consumed < input_len only when 192 KiB (or the
+ *      caller's room, if that is more) are waiting unread on the device already: the rest is to be offered
+ *      again, as with the reference.  A caller written against the contract ("consumed bytes must not be
+ *      offered again, the others must") behaves identically.
+ *   2. With more than 256 KiB of received input a call with NON-EMPTY input may return (consumed, 0)
+ *      without a decode attempt (attempts are then made when the stream has grown by 1/8 or by 64 KiB,
  *      and on every EMPTY input).  A caller must therefore conclude "truncated" (the reference's InsufficientInput,
  *      src/decompress.rs:1135-1136) only after a read with empty input has produced nothing and
  *      is_done is still false -- which is what the reference's own harness and the png crate do at
- *      the end of their input anyway. */
+ *      the end of their input anyway.
+ * Device memory (round 5): like the reference, which keeps its tables and needs the last 32 KiB of the caller's
+ * buffer (src/decompress.rs:96-113, 1067-1070), the object keeps what its resume point needs and no more -- the
+ * unread input, a copy of the current block's header, 32 KiB of history and the window with what has been decoded
+ * ahead of it: well under 1 MiB for a 16 KiB window, whatever the stream's length (fdh_decompressor_device_bytes). */
 typedef struct fdh_decompressor fdh_decompressor;
 fdh_decompressor *fdh_decompressor_new(void);
 void fdh_decompressor_free(fdh_decompressor *d);
@@ -277,6 +283,9 @@ uint64_t fdh_decompressor_attempts(const fdh_decompressor *d);
  * stopped (fdh_inflate_batch_resumable), so for a stream of N decoded bytes this stays close to N however the
  * input and the room arrive (rounds 1-3: every attempt started at the first byte). */
 uint64_t fdh_decompressor_decoded_bytes(const fdh_decompressor *d);
+/* Introspection: the most device memory the object's buffers (input tail + header copy, output slot, one
+ * record of metadata) have held together, in bytes. */
+uint64_t fdh_decompressor_device_bytes(const fdh_decompressor *d);
 int fdh_decompressor_read(fdh_decompressor *d, const uint8_t *input, size_t input_len,
                           uint8_t *output, size_t output_len, size_t output_position,
                           size_t *consumed, size_t *produced, uint32_t *stream_status);

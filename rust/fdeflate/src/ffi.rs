@@ -69,6 +69,8 @@ extern "C" {
     pub fn fdh_decompressor_attempts(d: *const fdh_decompressor) -> u64;
     /// Introspection (not part of the reference API): output bytes decoded by all attempts together.
     pub fn fdh_decompressor_decoded_bytes(d: *const fdh_decompressor) -> u64;
+    /// Introspection (not part of the reference API): the most device memory the object's buffers have held, in bytes.
+    pub fn fdh_decompressor_device_bytes(d: *const fdh_decompressor) -> u64;
     pub fn fdh_decompressor_read(d: *mut fdh_decompressor, input: *const u8, input_len: usize, output: *mut u8,
                                  output_len: usize, output_position: usize, consumed: *mut usize,
                                  produced: *mut usize, stream_status: *mut u32) -> c_int;

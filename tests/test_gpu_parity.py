@@ -150,8 +150,8 @@ def test_valid_streams_every_decoder_variant(harness):
 def test_landing_decoder_alone(harness):
     """inflate_seg3_kernel on its own (FDH_FLAG_LANDING_ONLY: what it leaves stays PENDING), with its lean
     and with the general writing pass: every stream it reports is right -- status, length, bytes, Adler-32
-    against the oracle -- and it takes every ultra-fast stream (but the empty buffer's: shorter than the fixed
-    prefix + 44 bits, left to the interval kernel) of the bench's three kinds of buffers (noisy
+    against the oracle -- and it takes every ultra-fast stream up to 70 000 bytes (but the empty buffer's: shorter
+    than the fixed prefix + 44 bits, left to the interval kernel) of the bench's three kinds of buffers (noisy
     rows, every other row zero, all zero), short ones and long ones, in exact and loose slots, at every
     alignment of input and slot (the harness packs back to back with odd guard slots in between)."""
     from fdeflate_amd import synth
@@ -171,8 +171,9 @@ def test_landing_decoder_alone(harness):
         took = 0
         for i, name in enumerate(names):
             if st[i] == 0xFFFFFFFF:
-                # (the only streams it may pass on: shorter than the fixed prefix + 44 bits -- the empty buffer)
-                assert len(blobs[i]) * 8 < 429 + 44, (name, len(blobs[i]), flags)
+                # (what it may pass on: streams shorter than the fixed prefix + 44 bits -- the empty buffer -- and
+                #  streams whose lanes' shares outgrow its check-point slots; never one of the bench's 64 KiB)
+                assert len(blobs[i]) * 8 < 429 + 44 or caps[i] > 70017, (name, len(blobs[i]), flags)
                 took += 1
                 continue
             took += 1
