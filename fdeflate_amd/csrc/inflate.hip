@@ -111,6 +111,7 @@ __device__ __forceinline__ ResumePoint resume_point(const InflateBatchArgs& a, c
         rp.opos = v.z;
         rp.adler = v.w;
         rp.valid = v.x != 0 ? 1u : 0u;
+        if (rp.bit == rp.hdr_bit) rp.step = STEP_START;  // (a block header is where a step starts, whoever left the point)
     }
     return rp;
 }
@@ -233,6 +234,7 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
             first.opos = v.z;
             first.adler = v.w;
             first.valid = v.x != 0 ? 1u : 0u;
+            if (first.bit == first.hdr_bit) first.step = STEP_START;
             if (first.valid && first.step != STEP_UNKNOWN) {
                 rp = first;
                 r = inf.run_from<false>(rp);

@@ -161,6 +161,7 @@ struct fdh_decompressor {
     uint64_t res_hdr_bit = 0, res_bit = 0;
     size_t res_out = 0;
     uint32_t res_adler = 0, res_step = 0;
+    uint32_t lz_unknown = 0;  // attempts in a row whose resume point came without its step state (below)
     uint64_t decoded = 0;     // output bytes decoded by all attempts together (introspection: N for a stream of N bytes
                               // that is never decoded twice)
     size_t peak_bytes = 0;    // the most device memory the three buffers have held together
@@ -228,6 +229,7 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     //  can be dropped then, and all input is taken)
     static const bool no_resume = std::getenv("FDH_STREAM_NO_RESUME") != nullptr;
     static const bool trace = std::getenv("FDH_STREAM_TRACE") != nullptr;  // one line per attempt on stderr
+    static const bool no_lz = std::getenv("FDH_STREAM_NO_LZ") != nullptr;  // (A/B: every attempt without the LZ-window kernel)
 
     const size_t room = output_len - output_position;
     // take the input: all of it, unless enough is waiting unread on the device already (src/decompress.rs:167-170:
@@ -366,6 +368,14 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
         rec.header_bit -= 8u * (uint32_t)kHead;
         rec.bit -= 8u * (uint32_t)kHead;
     }
+    // A resume point must know its place among the reference's table steps (a literal that is the second of a pair is
+    // not where a step starts): the serial decoder, asked to take a stream up at a point that does not, may have to go
+    // back to a point that does -- in the end to the stream's first byte (inflate.hip, general_one), which is no longer
+    // here.  The tile decoders keep track of the steps, the LZ-window kernel does not: when nothing behind it gets far
+    // enough to tell -- a stretch of nothing but literals whose codes pair up -- the point comes back with step state
+    // 0.  Such an attempt is made again without the LZ-window kernel (3-4 x slower, tools/streamtime.py), and a stream
+    // that does it twice in a row goes without from then on.
+    bool without_lz = no_lz || d->lz_unknown >= 2;
     for (;;) {
         {   // (what lies in front of the resume point, and what has been decoded ahead of the caller, stays)
             const size_t keep_to = std::max(d->ahead_have, d->res_valid ? d->res_out : 0);
@@ -386,7 +396,7 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
         HIP_TRY(hipStreamSynchronize(sq));  // (`meta` is a stack array)
         uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
         int rc = fdh_inflate_batch_resumable(d->in.p + in_at, m, d->out.p, m + 2, res, res + 1, res + 2, 1,
-                                             (d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u) | (go_on ? FDH_FLAG_RESUME_IN : 0u),
+                                             (d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u) | (go_on ? FDH_FLAG_RESUME_IN : 0u) | (without_lz ? FDH_FLAG_NO_LZ : 0u),
                                              reinterpret_cast<fdh_resume_point*>(m + 6), sq);
         if (rc != FDH_SUCCESS) return rc;
         HIP_TRY(hipMemcpyAsync(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost, sq));
@@ -394,12 +404,22 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
         d->attempts++;
         const uint32_t st1 = host_res[1];
         if (trace)
-            std::fprintf(stderr, "attempt %llu: in_total %zu tail_base %zu hdr_src %zd out_base %zu cap %zu go_on %d whole %d rec{h %u s %u b %u o %u} res{h %llu b %llu o %zu} -> st %u len %u got{h %u b %u o %u}\n",
+            std::fprintf(stderr, "attempt %llu: in_total %zu tail_base %zu hdr_src %zd out_base %zu cap %zu go_on %d whole %d rec{h %u s %u b %u o %u} res{h %llu b %llu o %zu} -> st %u len %u got{h %u s %u b %u o %u}\n",
                          (unsigned long long)d->attempts, d->in_total, d->tail_base, (ssize_t)d->hdr_src, d->out_base, cap, (int)go_on, (int)whole,
                          rec.header_bit & 0x3FFFFFFFu, rec.header_bit >> 30, rec.bit, rec.out_bytes, (unsigned long long)d->res_hdr_bit,
-                         (unsigned long long)d->res_bit, d->res_out, st1, host_res[0], host_res[4] & 0x3FFFFFFFu, host_res[5], host_res[6]);
+                         (unsigned long long)d->res_bit, d->res_out, st1, host_res[0], host_res[4] & 0x3FFFFFFFu, host_res[4] >> 30, host_res[5], host_res[6]);
         const bool classified = st1 == FDH_STREAM_OK || st1 == FDH_WRONG_CHECKSUM || st1 == FDH_OUTPUT_TOO_LARGE ||
                                 st1 == FDH_INSUFFICIENT_INPUT;
+        if (!no_resume && (st1 == FDH_OUTPUT_TOO_LARGE || st1 == FDH_INSUFFICIENT_INPUT)) {
+            const bool stepless = host_res[4] != 0 && (host_res[4] >> 30) == 0 && (host_res[4] & 0x3FFFFFFFu) != host_res[5];
+            if (!without_lz) {
+                d->lz_unknown = stepless ? d->lz_unknown + 1 : 0;
+                if (stepless) {
+                    without_lz = true;
+                    continue;
+                }
+            }
+        }
         if (classified) {
             const size_t from = go_on ? d->res_out : 0;
             const size_t to = d->out_base + host_res[0];
@@ -408,11 +428,8 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
         if (st1 == FDH_OUTPUT_TOO_LARGE || st1 == FDH_INSUFFICIENT_INPUT) {
             fdh_resume_point got;
             std::memcpy(&got, &host_res[4], sizeof(got));
-            // (none: the one this attempt started from still stands.  So it does when the new one does not know its place
-            //  among the reference's table steps -- step state 0, left by the LZ-window kernel when nothing behind it
-            //  got far enough to tell: the serial decoder could be sent back to the stream's first byte by such a point
-            //  (inflate.hip, general_one), and the first byte is no longer here.  Rare; the next attempt decodes that
-            //  stretch again.)
+            // (none: the one this attempt started from still stands.  So it does should a point come back without its
+            //  step state even from the tile decoders: the next attempt decodes that stretch again.)
             const bool at_header = (got.header_bit & 0x3FFFFFFFu) == got.bit;
             if (got.header_bit != 0 && ((got.header_bit >> 30) != 0 || at_header || no_resume)) {
                 // back to stream coordinates: a position in the tail, or (the header only) in the header's copy

@@ -2,7 +2,8 @@
     python tests/soak_gpu.py <first seed> <end seed>
 General encoder (level 1 / RLE) and the PNG kernels against the oracle on random shapes and
 contents, with guard bytes; several images per wavefront for the PNG pipeline; zlib / ultra-fast streams whole,
-cut and damaged; cut streams' partial lengths; the resumable batch (FDH_SOAK_ONLY=resume: the last two only)."""
+cut and damaged; cut streams' partial lengths; the resumable batch (FDH_SOAK_ONLY=resume: the last two only); the streaming object
+at the reference's footprint (FDH_SOAK_ONLY=stream)."""
 import os, sys, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -281,14 +282,77 @@ def resume_round(seed):
             assert int(ad[i]) == ead, (seed, i)
 
 
+def stream_round(seed):
+    """The streaming Decompressor at the reference's footprint (round 5): streams of 0.2-2 MB in both formats, whole,
+    cut short or with a flipped bit, the input offered in random pieces (what is not consumed is offered again), the
+    output drained through a random window with 32 KiB of history in front, as png does.  The bytes delivered are the
+    oracle's (all of them for a whole stream; for a cut one what the oracle's streaming decoder produces from the same
+    prefix; for a damaged one the bytes in front of the damage, to within two windows, and the oracle's error), and the device memory stays
+    under 1.5 MiB + three windows (stored blocks are taken up at their headers: 64 KiB at a time)."""
+    r = np.random.default_rng(seed)
+    for k in range(3):
+        c, a = _rand_stream(r, int(r.integers(200_000, 2_000_000)))
+        mut = int(r.integers(0, 4))
+        if mut == 1:
+            b = bytearray(c); b[int(r.integers(len(c) // 4, len(c)))] ^= 1 << int(r.integers(0, 8)); c = bytes(b)
+        if mut == 2:
+            c = c[:int(r.integers(len(c) // 4, len(c)))]
+        est, eout, _ = ob.decompress_bounded(c, len(a) + 4096)            # the one-shot classification
+        _, sout = ob.decompress_by_chunks(c, 0, len(a) + 4096)            # what a streaming decoder delivers from it
+        window = int(r.choice([1024, 4096, 16384, 65536]))
+        piece = int(r.choice([1, 3, 17, 64, 200])) * 1024
+        d = fd.Decompressor()
+        buf = bytearray(32768 + window)
+        got = bytearray()
+        pos = kpos = calls = idle = 0
+        status = 0
+        while not d.is_done():
+            calls += 1
+            assert calls < 200_000, (seed, k)
+            try:
+                cns, p = d.read(c[kpos:kpos + piece], buf, pos)
+            except fd.DecompressionError as e:
+                status = e.status
+                break
+            kpos += cns
+            got += buf[pos:pos + p]
+            pos += p
+            if pos > 32768:
+                buf[:32768] = buf[pos - 32768:pos]
+                pos = 32768
+            idle = idle + 1 if (p == 0 and cns == 0 and kpos >= len(c)) else 0
+            if idle >= 2:
+                break                       # the input is used up and an empty read produced nothing: cut short
+            assert os.environ.get("FDH_STREAM_NO_RESUME") or d.device_bytes() <= (3 << 19) + 3 * window, (seed, k, d.device_bytes(), window)
+        if est == 0:
+            assert status == 0 and d.is_done() and bytes(got) == a, (seed, k, status, len(got), len(a))
+        elif est == 2:                      # InsufficientInput: everything the prefix holds, and not done
+            assert status == 0 and not d.is_done() and bytes(got) == sout, (seed, k, status, len(got), len(sout))
+        elif est == 17:                     # (the damage made the stream longer than the one-shot slot: nothing to compare with)
+            pout = ob.decompress_by_chunks(c, max(256, len(c) // 4000), len(a) + 4096)[1]
+            m = min(len(got), len(pout))
+            assert bytes(got[:m]) == pout[:m], (seed, k)
+        else:
+            assert status == est, (seed, k, status, est)
+            # (the bytes in front of the damage, to within the call that fails -- here and there: the oracle's streaming
+            #  decoder fed small pieces delivers everything up to its failing call)
+            _, pout = ob.decompress_by_chunks(c, max(256, len(c) // 4000), len(a) + 4096)
+            m = min(len(got), len(pout))
+            assert bytes(got[:m]) == pout[:m] and len(got) + 2 * window + 600 >= len(pout), (seed, k, len(got), len(pout), window)
+
+
 ONLY = os.environ.get("FDH_SOAK_ONLY", "")
 for s in range(int(sys.argv[1]), int(sys.argv[2])):
+    if ONLY == "stream":
+        stream_round(8000 + s)
+        print("seed", s, "ok", flush=True)
+        continue
     if ONLY == "resume":
         cut_round(6000 + s); resume_round(7000 + s)
         print("seed", s, "ok", flush=True)
         continue
     if ONLY not in ("uf", "order"):
-        enc_round(1000 + s); png_round(2000 + s); dec_round(3000 + s); cut_round(6000 + s); resume_round(7000 + s)
+        enc_round(1000 + s); png_round(2000 + s); dec_round(3000 + s); cut_round(6000 + s); resume_round(7000 + s); stream_round(8000 + s)
     if ONLY != "order":
         uf_round(4000 + s)
     if s % 8 == 0 or ONLY == "order":
