@@ -971,10 +971,13 @@ __device__ __forceinline__ void lz_batch_plan(LzLds& L, LzBatch& B, LzFar& Fr, c
     B.dist = dist;
     B.send = pos - dist + min(len, dist);
     const int32_t src = (int32_t)(O + pos - dist);  // >= 0 (pass 2 checked it)
-    const bool small = valid && len <= 16 && dist >= len && qi0 + 16 <= kLzRing;
+    // (neither end may wrap around the ring: the BYTES of the match -- what a lane reads beyond them lies in the guard
+    //  bytes and is not used.  Round 4 asked for 16 bytes either side: one match in 110 went to the whole wavefront
+    //  for that alone, 100 of them per stream at ~1 200 cycles each.)
+    const bool small = valid && len <= 16 && dist >= len && qi0 + len <= kLzRing;
     const bool far = small && src + (int32_t)len <= ring_lo;  // (its ring index means nothing: the distance may exceed the ring)
     B.far = far;
-    B.simple = far || (small && src >= ring_lo && sidx0 + 16 <= kLzRing);
+    B.simple = far || (small && src >= ring_lo && sidx0 + len <= kLzRing);
     const uint32_t ring_at = (uint32_t)(reinterpret_cast<uintptr_t>(&L.ring[0]) & 0xFFFFu);
     const uint32_t far_at = (uint32_t)(reinterpret_cast<uintptr_t>(&L.u.w.stage[0]) & 0xFFFFu);
     B.sbase = far ? far_at + 16u * (uint32_t)lane : ring_at + sidx0;
