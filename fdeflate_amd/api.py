@@ -99,6 +99,8 @@ class Decompressor:
         return int(self._L.fdh_decompressor_device_bytes(self._d))
 
     def read(self, data, output, output_position):
+        """Decompressor::read (src/decompress.rs:179-337) -> (consumed, produced); raises DecompressionError.  What is
+        not consumed (more than 192 KiB, or the room, waiting unread on the device) is to be offered again."""
         data = bytes(data)
         mv = memoryview(output)
         if mv.readonly or mv.itemsize != 1 or not mv.contiguous:
