@@ -62,7 +62,7 @@ __device__ static const uint8_t kUfHeader[56] = {
 constexpr uint32_t kUfHeaderBits = 53 * 8 + 5;  // ultrafast.rs:87-88
 
 constexpr int kEncWaves = 4;             // wavefronts (= streams) per workgroup
-constexpr int kEncRingDw = 2048;         // 8 KiB bit ring per wavefront
+constexpr int kEncRingDw = 1024;         // 4 KiB bit ring per wavefront (round 5: 8 KiB kept a CU at 16 wavefronts)
 constexpr uint32_t kEncRingBits = kEncRingDw * 32;
 constexpr uint32_t kEncTileBudget = kEncRingBits - 1024;
 using BitRing = BitRingT<kEncRingDw>;
@@ -251,7 +251,11 @@ struct PngSource {
 };
 
 template <bool PNG>
-__global__ __launch_bounds__(kEncWaves * kWave) void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
+// Wavefronts per SIMD: five for the plain encoder (96 VGPRs, 12 B of scratch outside the tile loop, 4 KiB rings: 20 wavefronts
+// per CU, 2.91 -> 2.71 ms -- the vector ALUs were 86 % busy at four and still had stalls to fill), four for the one that
+// filters PNG rows on the way in (114 VGPRs: at 96 it spills 56 B into the loop, 6.45 -> 10.0 ms).
+__global__ __launch_bounds__(kEncWaves * kWave) __attribute__((amdgpu_waves_per_eu(PNG ? 4 : 5, PNG ? 4 : 5)))
+void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
     __shared__ EncLds lds;
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x / kWave;
