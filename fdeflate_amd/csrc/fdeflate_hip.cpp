@@ -313,18 +313,26 @@ int fdh_deflate_general_batch(const uint8_t* in, const uint64_t* in_off, uint8_t
     const uint64_t total_in = ends[1] - ends[0];
     // an empty input has a defined encoding (78 01 03 00 00 00 00 01), and a zero-element buffer has no address
     if (!in && total_in != 0) return fail(FDH_ERR_INVALID_ARGUMENT, "null data pointer");
-    // The parser runs one stream per lane and is bound by the latency of dependent loads: with a
-    // small batch it is given fewer lanes per wavefront and more wavefronts (8 per CU if the batch
-    // allows), capped so that the hash tables of the resident lanes stay below 8 GiB.
+    // The parser runs one stream per lane and is bound by the latency of dependent loads: what helps is wavefronts in
+    // flight.  A batch that does not fill the device with full wavefronts is given fewer lanes per wavefront and more
+    // wavefronts -- 8 per CU at level 1 (201 VGPRs: two per SIMD), 16 per CU for the RLE parser (126 VGPRs, no hash
+    // tables) -- and at level 1 the streams in flight are capped so that their hash tables (256 KiB each) stay below
+    // 16 GiB.  (Round 5: the cap was 8 GiB and applied to the RLE parser too, which has no tables: 65 536 streams ran as
+    // 1 024 wavefronts of 32 lanes in two rounds, one wavefront per SIMD.  All of them in flight: level 1 39.2 -> 31.7 ms,
+    // RLE 25.4 -> 21.9 ms.)
     const bool rle = mode == FDH_MODE_RLE;
     unsigned lanes = 64;
-    const uint64_t want_waves = (uint64_t)cus * 8;
+    const uint64_t want_waves = (uint64_t)cus * (rle ? 16 : 8);
     while (lanes > 4 && (n + lanes - 1) / lanes < want_waves) lanes /= 2;
     if (const char* e = std::getenv("FDH_GEN_LANES")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 64) lanes = (unsigned)v;
     }
-    const uint64_t max_resident = 32768;
+    uint64_t max_resident = rle ? (1ull << 40) : 65536;
+    if (const char* e = std::getenv("FDH_GEN_RESIDENT")) {
+        const long long v = std::atoll(e);
+        if (v >= 64 && v <= (1 << 20)) max_resident = (uint64_t)v;
+    }
     unsigned waves = (unsigned)std::min<uint64_t>((n + lanes - 1) / lanes, std::max<uint64_t>(1, max_resident / lanes));
     GenWork& w = g_gen_work[dev];
     std::lock_guard<std::mutex> lock(w.mutex);

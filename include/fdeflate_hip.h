@@ -184,7 +184,7 @@ uint64_t fdh_stored_size(uint64_t len);
  * Same argument convention as fdh_deflate_ultrafast_batch; slots of at least fdh_compress_bound(len_i)
  * bytes; out_len[i] = 0xFFFFFFFF if a slot was too small or the buffer exceeds 1 GiB.  The call
  * uses a per-device workspace (one 256 KiB hash table per resident stream at level 1, at most
- * 8 GiB; 8 bytes per 4 input bytes for the back-reference records), reads in_off[0] and in_off[n]
+ * 16 GiB; 8 bytes per 4 input bytes for the back-reference records), reads in_off[0] and in_off[n]
  * back to size it, and returns after the kernels have finished.
  */
 #define FDH_MODE_LEVEL1 1u
