@@ -1032,7 +1032,12 @@ struct InflaterT {
         // (Round 2: only the matches whose sources end in front of the tile were copied side by side, a
         // trip to memory per batch, the rest replayed one by one: 42 k of 144 k cycles per tile.)
         {
-            const uint32_t ring_top = opos + total;
+            // (+ 1: the scatter above may have written ONE byte behind the tile's output -- the second literal of a pair
+            //  the tile stopped at -- and in the ring that byte lies on top of position opos + total - kOutRing, which
+            //  therefore counts as gone.  It is in the slot: room keeps 80 bytes between the ring's end and `flushed`.
+            //  Round 5: found by the streaming soak, seed 1048 -- a match of the last tile in front of a cut read that
+            //  position and delivered one wrong byte 2 KiB in front of the end of the input.)
+            const uint32_t ring_top = opos + total + 1;
             const int64_t ring_lo = (int64_t)ring_top - kOutRing;
             constexpr int kBatches = (kMaxMatches + kWave - 1) / kWave;
             static_assert(kBatches == 3, "the loads below are written out for three batches");

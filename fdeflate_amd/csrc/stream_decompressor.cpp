@@ -304,9 +304,10 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     if (!attempt) return FDH_SUCCESS;  // (nothing of the prefix is left over here: that state is output-limited)
 
     const bool go_on = !no_resume && d->res_valid;
+    static const bool no_trim = std::getenv("FDH_STREAM_NO_TRIM") != nullptr;  // (A/B: resume points, but nothing is dropped)
     // ---- what the resume point no longer needs goes: output in front of its history (and of what the caller has not
     //      taken yet), input in front of its bit ----
-    if (go_on) {
+    if (go_on && !no_trim) {
         const size_t hist = d->res_out > kHistory ? d->res_out - kHistory : 0;
         const size_t ob = std::min(d->delivered, hist) & ~(size_t)15;
         if (ob >= d->out_base + kTrimStep) {
