@@ -374,8 +374,9 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     // back to a point that does -- in the end to the stream's first byte (inflate.hip, general_one), which is no longer
     // here.  The tile decoders keep track of the steps, the LZ-window kernel does not: when nothing behind it gets far
     // enough to tell -- a stretch of nothing but literals whose codes pair up -- the point comes back with step state
-    // 0.  Such an attempt is made again without the LZ-window kernel (3-4 x slower, tools/streamtime.py), and a stream
-    // that does it twice in a row goes without from then on.
+    // 0.  Such an attempt is made again without the LZ-window kernel (3-4 x slower, tools/streamtime.py) -- and, for an
+    // attempt from the stream's first byte, without the small-table kernel, whose points are stepless as well --, and
+    // a stream that does it twice in a row goes without from then on.
     bool without_lz = no_lz || d->lz_unknown >= 2;
     for (;;) {
         {   // (what lies in front of the resume point, and what has been decoded ahead of the caller, stays)
@@ -397,7 +398,7 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
         HIP_TRY(hipStreamSynchronize(sq));  // (`meta` is a stack array)
         uint32_t* res = reinterpret_cast<uint32_t*>(m + 4);
         int rc = fdh_inflate_batch_resumable(d->in.p + in_at, m, d->out.p, m + 2, res, res + 1, res + 2, 1,
-                                             (d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u) | (go_on ? FDH_FLAG_RESUME_IN : 0u) | (without_lz ? FDH_FLAG_NO_LZ : 0u),
+                                             (d->ignore_adler ? FDH_FLAG_IGNORE_ADLER32 : 0u) | (go_on ? FDH_FLAG_RESUME_IN : 0u) | (without_lz ? (FDH_FLAG_NO_LZ | FDH_FLAG_NO_FAST_GENERAL) : 0u),
                                              reinterpret_cast<fdh_resume_point*>(m + 6), sq);
         if (rc != FDH_SUCCESS) return rc;
         HIP_TRY(hipMemcpyAsync(host_res, res, sizeof(host_res), hipMemcpyDeviceToHost, sq));
