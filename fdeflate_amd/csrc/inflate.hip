@@ -684,13 +684,13 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
 // every 16th stream 0.5 KB, every 16th half the size).  Streams that do not start like an ultra-fast stream
 // (its first eight bytes) never get to the interval kernel: they go straight onto the list of the kernels
 // behind it -- handing 65 536 of them out one atomic at a time only to pass them on cost 0.8 ms.
-// counters: [0] long, [1] short, zeroed.
+// counters: [0..3] the streams of each class (SegOrder), zeroed.
 __global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, const uint64_t* in_off, uint32_t n, uint32_t* order,
                                                            uint32_t* counters, const uint32_t* canon_hdr, uint32_t* status,
                                                            uint32_t pending, uint32_t* list2, uint32_t second) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
-    const uint64_t thr = (in_off[n] - in_off[0]) / n / 2;
+    const uint64_t mean = (in_off[n] - in_off[0]) / n, thr = mean / 2;
     const bool valid = i < n;
     const uint64_t len = valid ? in_off[i + 1] - in_off[i] : 0;
     bool canon = valid && len * 8 >= kCanonBits;
@@ -707,21 +707,23 @@ __global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, co
     // (the other streams' list is walked from the front by persistent wavefronts too: the long ones are listed by
     //  the first launch of this kernel, the short ones behind them by a second launch, `second`)
     const bool other = valid && !canon && ((len >= thr) != (second != 0));
-    const bool big = canon && len >= thr && !second;
-    const bool small = canon && len < thr && !second;
-    const uint64_t mb = __ballot(big), ms = __ballot(small), mo = __ballot(other);
-    uint32_t base_b = 0, base_s = 0, base_o = 0;
-    if (lane == 0) {
-        if (mb) base_b = atomicAdd(&counters[0], (uint32_t)__popcll(mb));
-        if (ms) base_s = atomicAdd(&counters[1], (uint32_t)__popcll(ms));
-        if (mo) base_o = atomicAdd(&list2[0], (uint32_t)__popcll(mo));
-    }
-    base_b = __shfl(base_b, 0);
-    base_s = __shfl(base_s, 0);
-    base_o = __shfl(base_o, 0);
+    const uint32_t cls = seg_order_class(len, mean);
     const uint64_t below = (1ull << lane) - 1;
-    if (big) order[base_b + (uint32_t)__popcll(mb & below)] = i;
-    if (small) order[n + base_s + (uint32_t)__popcll(ms & below)] = i;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {  // the canonical streams by class: SegOrder
+        const bool mine = canon && !second && cls == k;
+        const uint64_t m = __ballot(mine);
+        if (m == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&counters[k], (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        const uint32_t r = base + (uint32_t)__popcll(m & below);
+        if (mine) order[k == 0 ? r : (k == 1 ? n - 1 - r : (k == 2 ? n + r : 2 * n - 1 - r))] = i;
+    }
+    const uint64_t mo = __ballot(other);
+    uint32_t base_o = 0;
+    if (lane == 0 && mo) base_o = atomicAdd(&list2[0], (uint32_t)__popcll(mo));
+    base_o = __shfl(base_o, 0);
     if (other) {
         status[i] = pending;
         list2[4 + base_o + (uint32_t)__popcll(mo & below)] = i;
@@ -750,8 +752,9 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
     // only pass on -- so a wavefront that passed on everything it was given takes twice as many next time.
     // (with a hand-out order: its long streams, then its short ones -- what does not look canonical is not in it)
     // (behind the landing decoder: only what that kernel listed)
-    const uint32_t n_long = a.order ? uni(a.order_counts[0]) : 0u;
-    const uint32_t n32 = a.src_list ? uni(a.src_list[0]) : (a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n);
+    SegOrder ord{0, 0, 0, 0};
+    if (a.order) ord = SegOrder{uni(a.order_counts[0]), uni(a.order_counts[1]), uni(a.order_counts[2]), uni(a.order_counts[3])};
+    const uint32_t n32 = a.src_list ? uni(a.src_list[0]) : (a.order ? ord.total() : (uint32_t)a.n);
     // (the first stream of a wavefront is its own number: 4 096 wavefronts after one counter at once is 80 us)
     const uint32_t n_waves = gridDim.x * kS2Waves;
     uint32_t cur = blockIdx.x * kS2Waves + threadIdx.x / kWave, end = cur + 1, take = 1;
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArg
         }
         if (cur >= n32) break;
         const uint32_t sid = a.src_list ? uni(a.src_list[4 + cur])
-                                        : (a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur);
+                                        : (a.order ? uni(a.order[ord.at((uint32_t)a.n, cur)]) : cur);
         took = seg2_decode(a, lds, ckpt, sid) || took;
         cur++;
     }
@@ -1134,9 +1137,9 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
         const bool seg3 = seg2 && !(flags & 0x10000u);  // the landing decoder in front of the interval decoder
         const unsigned s2blocks = std::min((unsigned)((n + fdh::kS2Waves - 1) / fdh::kS2Waves), (unsigned)cus);
         // (+ the hand-out order of the interval kernel when every wavefront gets several streams);
-        // layout: first list | 4 words: counters of stream_order_kernel | second list | order | third list | checkpoints
+        // layout: first list | 8 words: counters of stream_order_kernel (4 classes, [4] the LZ-window kernel's hand-out) | second list | order | third list | checkpoints
         const bool ordered = seg2 && n >= 4ull * s2blocks * fdh::kS2Waves && n <= 0x7FFFFFFFull;
-        const size_t list2_at = (size_t)(n + 4) + 4;
+        const size_t list2_at = (size_t)(n + 4) + 8;
         const size_t list3_at = list2_at + (size_t)(n + 4) + (ordered ? (size_t)(2 * n) : 0);
         const bool overlap = ordered && side != nullptr;
         const size_t list4_at = list3_at + (seg3 ? (size_t)(n + 4) : 0);  // (overlap: what the canonical kernels leave)
@@ -1157,7 +1160,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 e = hipMemsetAsync(list, 0, words_al * sizeof(uint32_t), stream);
             } else {
                 e = hipMemsetAsync(list, 0, 4 * sizeof(uint32_t), stream);
-                if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 8 * sizeof(uint32_t), stream);  // counters + second header
+                if (e == hipSuccess) e = hipMemsetAsync(list + (n + 4), 0, 12 * sizeof(uint32_t), stream);  // counters + second header
             }
             if (e != hipSuccess) {
                 (void)hipFreeAsync(list, stream);
@@ -1194,7 +1197,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                     b.only_pending = 1;
                     b.list = list + list2_at;
                     b.list_out = list + list5_at;
-                    b.lz_counter = list + (n + 4) + 2;  // (a spare word of stream_order_kernel's counters, zeroed above)
+                    b.lz_counter = list + (n + 4) + 4;  // (a spare word of stream_order_kernel's counters, zeroed above)
                     b.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes);
                     b.resume = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes);
                     hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, side, b);
@@ -1300,7 +1303,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             // a grid-stride loop, so a batch that is all canonical costs two near-empty launches
             const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 4096);  // persistent workgroups (16 per CU at most)
             if (e == hipSuccess && !(flags & 0x1000u)) {  // the LZ-window kernel: persistent wavefronts, FDH_LZ_WAVES_PER_CU per CU
-                a.lz_counter = list + (n + 4) + 2;  // (a spare word of stream_order_kernel's counters, zeroed above)
+                a.lz_counter = list + (n + 4) + 4;  // (a spare word of stream_order_kernel's counters, zeroed above)
                 a.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes);
 
                 // its leftovers: the list region the kernels in front are done with

@@ -35,6 +35,9 @@ constexpr uint32_t kS3PeriodBits = 2 * kS3PeriodPairs * kLitBits;  // most strea
 constexpr uint32_t kS3GroupBits = 2 * kS2Pairs * kLitBits;
 constexpr uint32_t kS3TailGuard = 256;          // bytes behind the end of a stream that a lane may load
 constexpr uint32_t kS3InCap = 3072;             // input image of the writing pass in this kernel's LDS layout
+constexpr int kS3Repeat = 64;                   // run tokens merged into one chain when the lean writer takes the stream
+constexpr uint32_t kS3FlatBits = 10;            // bits of a 258-byte run token of the prefix's code (symbol 285 + distance '0')
+constexpr uint32_t kS3PureFlag = 0x80000000u;   // checkpoint.y: the interval that starts here is a run chain behind a run chain
 
 struct Seg3Lds {
     uint32_t lit[kLitSize];        // step table (seg2_entry_build), at LDS offset 0
@@ -145,6 +148,12 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     // (uniform) a lane may load kS3TailGuard bytes past the end of its stream: the last stream(s) of the batch take the
     // range-checked loads
     const bool edge = in + ilen + kS3TailGuard > buf_hi;
+    // (uniform) the lean writer takes the stream: 16-B aligned slot, not within an input image of the end of the batch
+    // buffer.  Known here, because the counting pass may then merge up to kS3Repeat run tokens into a chain (the
+    // general writer: kS2Repeat) and mark the chains that follow a chain.
+    lean = !(a.flags & 0x80000u) && ((reinterpret_cast<uintptr_t>(a.out) + o0) & 15) == 0 && in + ilen + kS3InCap + 128 <= buf_hi;
+    const int reps = lean ? kS3Repeat : kS2Repeat;
+    const uint32_t pure_flag = lean ? kS3PureFlag : 0u;
     if (ours) {  // canonical prefix: lane k compares stream dword k
         bool mismatch = false;
         if (lane < 14) {
@@ -236,6 +245,23 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
         c -= wrap ? 32u : 0u;
     };
 
+    // A flat stretch: how many times (0..5) the 258-byte run token `tok10` is there again at the read position -- 50 stream
+    // bits compared with the token's own ten bits repeated (the two ring words behind the window must be there).
+    auto flat_more = [&](uint32_t tok10) __attribute__((always_inline)) {
+        const uint32_t o = (c & 63u) + 2;  // (2 <= o <= 33)
+        const unsigned long long A = ((unsigned long long)hi << 32) | lo;
+        const unsigned long long B = ((unsigned long long)rl[((Rw + 3) & 31) * 64] << 32) | rl[((Rw + 2) & 31) * 64];
+        const unsigned long long v = (A >> o) | (B << (64 - o));
+        const unsigned long long five = (unsigned long long)tok10 * ((1ull << 0) | (1ull << 10) | (1ull << 20) | (1ull << 30) | (1ull << 40));
+        const unsigned long long diff = ((v ^ five) & ((1ull << 50) - 1)) | (1ull << 50);
+        return (uint32_t)__builtin_ctzll(diff) / kS3FlatBits;
+    };
+    auto advance_flat = [&](uint32_t k) __attribute__((always_inline)) {  // k <= 5 tokens of kS3FlatBits bits
+        const uint32_t k1 = min(k, 3u);
+        advance(kS3FlatBits * k1);
+        advance(kS3FlatBits * (k - k1));
+    };
+
     S3T(2);
     // ---- guessed chain through the window (lanes 1..63); a run token is stepped over, anything else
     //      that is no literal slides on by one bit ----
@@ -250,9 +276,16 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
             pos = position();
             const bool parked = act && e == 0 && pos < leave;
             if (__any(parked)) {
-                const S3Tok t = s3_token(canon, window30());
+                const uint32_t w30 = window30();
+                const S3Tok t = s3_token(canon, w30);
                 advance(parked ? ((t.run != 0 && !t.bad) ? t.used : 1u) : 0u);
                 pos = position();
+                const bool flat = parked && t.run == 258 && !t.bad && t.used == kS3FlatBits && pos < leave;
+                if (__any(flat)) {  // a flat stretch: up to five more of the same token at once
+                    const uint32_t k = flat ? min(flat_more(w30 & ((1u << kS3FlatBits) - 1)), (leave - pos + kS3FlatBits - 1) / kS3FlatBits) : 0u;
+                    advance_flat(k);
+                    pos = position();
+                }
             }
         }
     }
@@ -268,13 +301,13 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     bool over = false;    // the chain has passed the target: no token ends there, the right neighbour's guess was wrong
     bool landed = !in_range;
     bool need = in_range;  // lanes that count in this round (the first: all; then the right neighbours of chains that went over)
-    auto cut = [&](bool doit) __attribute__((always_inline)) {
+    auto cut = [&](bool doit, uint32_t flag = 0u) __attribute__((always_inline)) {
         if (doit) {
             if (slot >= kS2Slots) {
                 fault = true;
             } else {
                 const uint32_t cnt = c >> 6;
-                ckrow[slot * S2_CK_STRIDE] = make_uint2((pos - seg_bit0) | (bl << kS2PosBits), cnt - 16 * bl);
+                ckrow[slot * S2_CK_STRIDE] = make_uint2((pos - seg_bit0) | (bl << kS2PosBits), (cnt - 16 * bl) | flag);
                 slot++;
             }
             m = 0;
@@ -306,8 +339,9 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
         for (int nch = 0; nch < 48 && __any(more); nch++) {
             bool go = more;
             uint32_t chain = 0;
-            for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
-                const S3Tok t = s3_token(canon, window30());
+            for (int rep = 0; rep < reps && __any(go);) {
+                const uint32_t w30 = window30();
+                const S3Tok t = s3_token(canon, w30);
                 const bool is_run = go && t.run != 0 && !t.bad;
                 const bool is_eob = go && rep == 0 && t.eob && lane == last;
                 over = over || (is_run && pos + t.used > target);
@@ -320,13 +354,30 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
                 advance(is_run ? t.used : 0u);
                 pos = position();
                 go = is_run && t.run == 258 && pos < target;
+                rep++;
+                // a flat stretch: the same 258-byte token again and again -- up to five more of them at once, by
+                // comparing 50 stream bits with the token's own bits repeated (lean streams only: the chains get long)
+                const bool flat = lean && go && t.used == kS3FlatBits;
+                if (__any(flat) && rep + 5 <= reps) {
+                    refill();
+                    uint32_t k = flat ? flat_more(w30 & ((1u << kS3FlatBits) - 1)) : 0u;      // tokens that repeat (0..5)
+                    k = min(k, (target - pos + kS3FlatBits - 1) / kS3FlatBits);           // ... and start in front of the target
+                    over = over || (k != 0 && pos + kS3FlatBits * k > target);
+                    chain += 258u * k;
+                    advance_flat(k);
+                    pos = position();
+                    go = go && pos < target;
+                    rep += 5;
+                }
             }
             c += chain << 6;
             bl += chain >= kS2LongRun ? chain / 16 - 1 : 0u;
-            cut(more && chain != 0);
-            // on to the next chain only where the lane sits on a run token again (anything else: back to the look-ups)
+            // on to the next chain only where the lane sits on a run token again (anything else: back to the look-ups);
+            // the interval that starts behind this chain is then a chain and nothing else, in front of it zeros: marked
             const S3Tok t = s3_token(canon, window30());
-            more = more && chain != 0 && !stopped && !fault && pos < target && t.run != 0 && !t.bad;
+            const bool again = more && chain != 0 && !stopped && !fault && pos < target && t.run != 0 && !t.bad;
+            cut(more && chain != 0, again ? pure_flag : 0u);
+            more = again;
             if (__any(more)) refill();
         }
     };
@@ -472,8 +523,6 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     plan.ni = __builtin_amdgcn_readlane(incl_n, kWave - 1);
     plan.tb = tb;
     plan.seg = seg;
-    lean = !(a.flags & 0x80000u) && __builtin_amdgcn_readlane(incl_b, kWave - 1) == 0 &&
-           ((reinterpret_cast<uintptr_t>(a.out) + o0) & 15) == 0 && in + ilen + kS3InCap + 128 <= buf_hi;
     S3T(7);
     return true;
 }
@@ -550,13 +599,16 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
     };
     // the intervals of the round in c0 (start) / c1 (end): x = stream bit of the first token, y = output bytes in
     // front of it; how many of them fit the two images: n
+    // (a checkpoint holds its bytes less the whole lines its run chains left out of the general writer's image: here
+    //  image positions are output positions, the lines are added back)
     uint2 c0, c1;
-    bool valid;
+    bool valid, pure;
     auto settle = [&](const Fetch& t) __attribute__((always_inline)) {
         const uint32_t posmask = (1u << kS2PosBits) - 1;
-        c0 = make_uint2(t.pbase + (t.e0.x & posmask), t.qbase + t.e0.y);
-        c1 = make_uint2(t.pbase + (t.e1.x & posmask), t.qbase + t.e1.y);
+        c0 = make_uint2(t.pbase + (t.e0.x & posmask), t.qbase + (t.e0.y & ~kS3PureFlag) + 16 * (t.e0.x >> kS2PosBits));
+        c1 = make_uint2(t.pbase + (t.e1.x & posmask), t.qbase + (t.e1.y & ~kS3PureFlag) + 16 * (t.e1.x >> kS2PosBits));
         valid = t.valid;
+        pure = t.valid && (t.e0.y & kS3PureFlag) != 0;
     };
     uint32_t own = 0;  // per lane: the owner of this lane's interval of the current round
     {
@@ -566,13 +618,25 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
     }
     uint32_t n = 0, ib = 0;
     const uint8_t* a0 = in;
+#ifdef FDH_S3_DEBUG
+    uint32_t s3_why[3] = {0, 0, 0};
+#endif
     auto stage_c = [&](uint32_t wq_) __attribute__((always_inline)) {
         const uint8_t* g0 = in + ((c0.x - 2) >> 3);
         a0 = reinterpret_cast<const uint8_t*>(uni64(reinterpret_cast<uintptr_t>(g0)) & ~(uintptr_t)15);
         ib = (uint32_t)(g0 - a0);
-        const bool fits = valid && ib + kS2InReach <= kS3InCap && (c1.y - wq_) + kS2OutReach <= kS2OutCap;
+        // (what a lane writes into the image are the literals of its one group, at most 3 kS2Meter bytes from its start:
+        //  a run chain behind them leaves the image as it is, however long, and a chain behind a chain needs no image)
+        const bool fits = valid && ib + kS2InReach <= kS3InCap && (pure || (c0.y - wq_) + kS2OutReach <= kS2OutCap);
         const uint64_t fit_mask = __ballot(fits);
         n = fit_mask == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fit_mask);
+#ifdef FDH_S3_DEBUG
+        if (n < (uint32_t)kWave) {  // why the round ends in front of lane n: no interval left / the input image / the output image
+            const bool v_ = __builtin_amdgcn_readlane((int)valid, (int)n) != 0;
+            const bool i_ = __builtin_amdgcn_readlane((int)(ib + kS2InReach <= kS3InCap), (int)n) != 0;
+            s3_why[!v_ ? 0 : (!i_ ? 1 : 2)]++;
+        }
+#endif
     };
     auto request = [&](const uint8_t* from) __attribute__((always_inline)) {
         const uint8_t* p = from + 16 * (uint32_t)lane;
@@ -594,7 +658,10 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
     request(a0);
     uint32_t stores_behind = 0;
     S3W_DECL;
+    uint32_t dbg_rounds = 0;
+    (void)dbg_rounds;
     while (f0 < ni) {
+        dbg_rounds++;
         S3W(7);
         const uint32_t wq = qa - 16;  // (mod 2^32: the image starts one piece in front of what has not been flushed)
         if (n == 0) {
@@ -614,7 +681,7 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         uint32_t wi = act ? (ib_cur >> 2) + 2 : 2u;
         uint32_t lo = imgA[wi - 2], hi = imgA[wi - 1];
         uint32_t boff = 8 * (ib_cur & 3) + ((pos0 - 2) & 7);
-        uint32_t oaddr = ldsB + (q0 - wq);
+        uint32_t oaddr = ldsB + (pure ? 16u : q0 - wq);  // (a chain behind a chain: its lane marks time, ORs nothing)
         S3W(1);
         {
             uint32_t c = boff | (oaddr << 6), acc = 0, ra = ldsA + 4 * wi;
@@ -627,32 +694,17 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         // waiting for them -- and with them for this round's stores and the next input image -- at the loop's head)
         S3W(2);
         asm volatile("" ::"v"(nx.e0.x), "v"(nx.e0.y), "v"(nx.e1.x), "v"(nx.e1.y));
-        uint32_t pos = 8 * (in_off0 + 4 * (wi - 2)) + boff + 2;  // stream bit of the lane's next token
-        // ---- a lane that is not at the end of its interval sits on the run chain that ends it ----
-        bool go = act && pos < pos1;
-        if (__any(go)) {
-            const bool mine = go;
-            uint32_t chain = 0;
-            for (int rep = 0; rep < kS2Repeat && __any(go); rep++) {
-                const S3Tok t = s3_token(canon, __builtin_amdgcn_alignbit(hi, lo, boff) >> 2);
-                const bool step = go && t.run != 0 && !t.bad;
-                bad = bad || (go && rep == 0 && !step);
-                chain += step ? t.run : 0u;
-                const uint32_t adv = step ? t.used : 0u;
-                pos += adv;
-                boff += adv;
-                const bool wrap = boff >= 32;
-                const uint32_t nw = imgA[wi];
-                lo = wrap ? hi : lo;
-                hi = wrap ? nw : hi;
-                wi += wrap ? 1u : 0u;
-                boff &= 31u;
-                go = step && t.run == 258 && pos < pos1;
-            }
+        const uint32_t pos = 8 * (in_off0 + 4 * (wi - 2)) + boff + 2;  // stream bit of the lane's next token
+        // ---- a lane that is not at the end of its interval sits on the run chain that ends it: the counting pass has
+        //      decoded that chain from these very bits (pos1 is where it ends) and a run repeats the byte in front of it
+        //      -- a zero, from any encoder that does what the reference's does (src/compress/ultrafast.rs:46-66), so the
+        //      zero-initialised image is left as it is; a run of anything else sends the stream to the general writers ----
+        {
+            const bool mine = act && !pure && pos < pos1;
             wave_sync();
             const uint32_t xi = mine ? oaddr - ldsB : 16u;
             const uint32_t front = imgB8[xi - 1];
-            bad = bad || (mine && (pos != pos1 || front != 0 || chain >= kS2LongRun || wq + xi == 0));
+            bad = bad || (mine && (front != 0 || wq + xi == 0));
         }
         if (__any(bad)) {
             bad = true;
@@ -663,6 +715,14 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         const bool final_round = f0 + n >= ni;
         const uint32_t qa_new = final_round ? (qf_new + 15) & ~15u : max(qa, qf_new & ~127u);
         const uint32_t xa_new = qa_new - wq, n_cur = n;
+        // (a round that ends in a long run chain: the image ends in front of qa_new -- what lies beyond it are the
+        //  chain's zeros, stored straight to the slot, 1 KiB per instruction, nothing for the Adler-32 sums; issued in
+        //  front of the input request, so that the wait for that request need not count them)
+        const uint32_t xa_img = min(xa_new, kS2OutCap);
+        for (uint32_t x = xa_img + 16 * (uint32_t)lane; x < xa_new; x += 16 * kWave) {
+            const uint32_t v = wq + x;
+            if (v + 16 <= total) *reinterpret_cast<uint4*>(op + v) = make_uint4(0, 0, 0, 0);
+        }
         // ---- the next round: its intervals, how many fit, its input bytes (this round is done with the image) ----
         settle(nx);
         own = nx.sg;
@@ -670,7 +730,7 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
             stage_c(qa_new - 16);
             request(a0);
         }
-        stores_behind = final_round ? 64u : (xa_new - 16 + 1023) / 1024;
+        stores_behind = final_round ? 64u : (xa_img - 16 + 1023) / 1024;
         S3W(4);
         // ---- flush: whole 128-B lines of the image (everything once the stream ends), one store per KiB; two pieces
         //      per trip, both read before the first is used ----
@@ -687,9 +747,9 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
             ad_a += sum;
             ad_b += (unsigned long long)(total - v) * sum;
         };
-        for (uint32_t x = 16 + 16 * (uint32_t)lane; __any(x < xa_new); x += 32 * kWave) {
+        for (uint32_t x = 16 + 16 * (uint32_t)lane; __any(x < xa_img); x += 32 * kWave) {
             const uint32_t x2 = x + 16 * kWave, v = wq + x, v2 = wq + x2;
-            const bool g1 = x < xa_new && v + 16 <= total, g2 = x2 < xa_new && v2 + 16 <= total;
+            const bool g1 = x < xa_img && v + 16 <= total, g2 = x2 < xa_img && v2 + 16 <= total;
             uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1;
             if (g1) q1 = *reinterpret_cast<const uint4*>(imgB8 + x);
             if (g2) q2 = *reinterpret_cast<const uint4*>(imgB8 + x2);
@@ -703,7 +763,8 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
             if (total & 15u) {  // the last piece of the stream: its own bytes only
                 const uint32_t v = total & ~15u, x = v - wq;
                 if ((uint32_t)lane == (((x - 16) >> 4) & 63u)) {
-                    const uint4 q = *reinterpret_cast<const uint4*>(imgB8 + x);
+                    uint4 q = make_uint4(0, 0, 0, 0);  // (beyond the image: the zeros of the chain the stream ends with)
+                    if (x + 16 <= kS2OutCap) q = *reinterpret_cast<const uint4*>(imgB8 + x);
                     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
                     for (uint32_t kk = 0; kk < (total & 15u); kk++) {
                         const uint32_t byte = (w[kk >> 2] >> (8 * (kk & 3))) & 0xFFu;
@@ -720,7 +781,7 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
             const uint32_t used_end = min(kS2OutCap, (keep_end + kS2OutReach + 15) & ~15u);
             const uint32_t sx = src0 + 16 * (uint32_t)lane;
             uint4 keep = make_uint4(0, 0, 0, 0);
-            if (sx < keep_end) keep = *reinterpret_cast<const uint4*>(imgB8 + sx);
+            if (sx < keep_end && sx + 16 <= kS2OutCap) keep = *reinterpret_cast<const uint4*>(imgB8 + sx);
             wave_sync();  // every lane has read before any lane writes
             *reinterpret_cast<uint4*>(imgB8 + 16 * (uint32_t)lane) = keep;
             for (uint32_t x = 16 * (uint32_t)(lane + kWave); x < used_end; x += 16 * kWave)
@@ -732,6 +793,12 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         S3W(6);
     }
     S3W_OUT;
+    S3N(12, dbg_rounds);
+    S3N(13, ni);
+#ifdef FDH_S3_DEBUG
+    S3N(14, s3_why[1]);
+    S3N(15, s3_why[2]);
+#endif
     if (__any(bad)) {
         if (lane == 0) seg_leave_pending(a, sid);
         return false;

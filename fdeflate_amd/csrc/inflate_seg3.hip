@@ -3,6 +3,11 @@
 
 namespace fdh {
 
+#ifdef FDH_S3_DEBUG
+// per wavefront: [0] = streams taken, [1 + 2k] = stream id, [2 + 2k] = s_memrealtime (100 MHz) when it was done; [63] = start
+__device__ uint32_t g_s3seq[4096 * 64];
+#endif
+
 // Landing decoder (inflate_seg3.h) in front of the interval decoder: the same hand-out, the same writing pass,
 // its own counting pass; what it does not take is listed for the interval kernel.
 __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArgs a) {
@@ -21,12 +26,18 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArg
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     uint2* const ckpt = a.ckpt + (size_t)(blockIdx.x * kS2Waves + threadIdx.x / kWave) * kS2CkptPerWave;
-    const uint32_t n_long = a.order ? uni(a.order_counts[0]) : 0u;
-    const uint32_t n32 = a.order ? n_long + uni(a.order_counts[1]) : (uint32_t)a.n;
+    SegOrder ord{0, 0, 0, 0};
+    if (a.order) ord = SegOrder{uni(a.order_counts[0]), uni(a.order_counts[1]), uni(a.order_counts[2]), uni(a.order_counts[3])};
+    const uint32_t n32 = a.order ? ord.total() : (uint32_t)a.n;
     // (the first stream of a wavefront is its own number: 4 096 wavefronts after one counter at once is 80 us)
     const uint32_t n_waves = gridDim.x * kS2Waves;
     uint32_t cur = blockIdx.x * kS2Waves + threadIdx.x / kWave, end = cur + 1, take = 1;
     bool took = true;
+#ifdef FDH_S3_DEBUG
+    const uint32_t wv_ = blockIdx.x * kS2Waves + threadIdx.x / kWave;
+    uint32_t nseq_ = 0;
+    if (lane == 0 && wv_ < 4096) g_s3seq[wv_ * 64 + 63] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     for (;;) {
         if (cur == end) {
             take = took ? 1u : min(16u, 2 * take);
@@ -38,7 +49,18 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArg
             end = min(n32, cur + take);
         }
         if (cur >= n32) break;
-        took = seg3_decode(a, lds, ckpt, a.order ? uni(a.order[cur < n_long ? cur : (uint32_t)a.n + (cur - n_long)]) : cur) || took;
+#ifdef FDH_S3_DEBUG
+        const uint32_t sid_ = a.order ? uni(a.order[ord.at((uint32_t)a.n, cur)]) : cur;
+#endif
+        took = seg3_decode(a, lds, ckpt, a.order ? uni(a.order[ord.at((uint32_t)a.n, cur)]) : cur) || took;
+#ifdef FDH_S3_DEBUG
+        if (lane == 0 && wv_ < 4096 && nseq_ < 30) {
+            g_s3seq[wv_ * 64 + 1 + 2 * nseq_] = sid_;
+            g_s3seq[wv_ * 64 + 2 + 2 * nseq_] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            nseq_++;
+            g_s3seq[wv_ * 64] = nseq_;
+        }
+#endif
         cur++;
     }
 }
@@ -59,6 +81,11 @@ extern "C" int fdh_debug_s3time(uint32_t* host) {
     if (hipMemcpyFromSymbol(host + 4096 * 16 + 16, HIP_SYMBOL(fdh::g_s2time), 4096 * 16 * 4) != hipSuccess) return 4;
 #endif
     if (hipMemcpyFromSymbol(host + 4096 * 16 + 16 + 4096 * 16, HIP_SYMBOL(fdh::g_s3wtime), 4096 * 8 * 4) != hipSuccess) return 5;
+    return 0;
+}
+extern "C" int fdh_debug_s3seq(uint32_t* host) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_s3seq), 4096 * 64 * 4) != hipSuccess) return 2;
     return 0;
 }
 #endif

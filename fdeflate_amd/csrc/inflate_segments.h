@@ -148,9 +148,29 @@ struct SegArgs {
     const uint32_t* canon_lit2;  // ... and its decode table (CanonTables::lit2)
     uint32_t* list2; // nullable (interval kernel): the list of the kernel BEHIND the segment kernel -- streams without
                      // the ultra-fast prefix go there directly, the segment kernel would only look at them and pass them on
-    const uint32_t* order;  // nullable (interval kernel): the order in which the streams are handed out (long ones first, [0 ..); short ones [n ..))
-    const uint32_t* order_counts;  // ... and how many of each
+    const uint32_t* order;  // nullable (landing / interval kernel): the order in which the streams are handed out, 2 n words
+                            // filled by stream_order_kernel from both ends of each half (SegOrder)
+    const uint32_t* order_counts;  // ... and how many streams of each of the four classes
 };
+
+// Hand-out order of the landing / interval kernels (stream_order_kernel): four classes by compressed length, longest
+// first, so that what the wavefronts take last is short and they finish together.  Class 0 fills order[0 ..) upwards,
+// class 1 order[n - 1 ..) downwards, class 2 order[n ..) upwards, class 3 order[2 n - 1 ..) downwards.
+struct SegOrder {
+    uint32_t n0, n1, n2, n3;
+    __device__ __forceinline__ uint32_t total() const { return n0 + n1 + n2 + n3; }
+    __device__ __forceinline__ uint32_t at(uint32_t n, uint32_t cur) const {  // index into `order` of the cur-th stream handed out
+        if (cur < n0) return cur;
+        cur -= n0;
+        if (cur < n1) return n - 1 - cur;
+        cur -= n1;
+        if (cur < n2) return n + cur;
+        return 2 * n - 1 - (cur - n2);
+    }
+};
+__device__ __forceinline__ uint32_t seg_order_class(uint64_t len, uint64_t mean) {
+    return len >= mean ? 0u : (2 * len >= mean ? 1u : (8 * len >= mean ? 2u : 3u));
+}
 
 // Leaves stream `sid` to the wave-per-stream kernels (lane 0 only).
 __device__ __forceinline__ void seg_leave_pending(const SegArgs& a, uint64_t sid) {
