@@ -130,6 +130,13 @@ __device__ __forceinline__ uint32_t seg2_count_group(uint32_t pairs, uint32_t rb
 // a dword, and a lane may run on past the end of its interval -- what it then decodes are the
 // stream's real next symbols, i.e. exactly what the lane behind it stores to the same bytes.
 // On return the accumulator has been stored; returns the last entry looked up.
+#ifdef FDH_X_NO_OR  // timing experiment (wrong bytes): the writing group without its LDS atomics
+#define S2_OR_STEP "  s_nop 0\n"
+#define S2_WAIT_E "  s_waitcnt lgkmcnt(0)\n"
+#else
+#define S2_OR_STEP "  ds_or_b32 %[wa], %[x]\n"
+#define S2_WAIT_E "  s_waitcnt lgkmcnt(1)\n"
+#endif
 __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& lo, uint32_t& hi, uint32_t& c, uint32_t& ra,
                                                      uint32_t& acc) {
     // The store of a step is issued BEHIND the table read of the next step (the LDS works in order:
@@ -152,10 +159,10 @@ __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& l
         "  v_lshrrev_b64 " S2_SHF ", %[c], " S2_WIN "\n"
         "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
         "  ds_read_b32 %[e], %[t]\n"
-        "  ds_or_b32 %[wa], %[x]\n"  // the step before (at the start: the accumulator as it came in)
+        S2_OR_STEP  // the step before (at the start: the accumulator as it came in)
         "  v_lshrrev_b32 %[u], 6, %[c]\n"
         "  v_and_b32 %[wa], -4, %[u]\n"
-        "  s_waitcnt lgkmcnt(1)\n"
+        S2_WAIT_E
         "  v_lshrrev_b32 " S2_VLO ", 8, %[e]\n"
         "  v_lshlrev_b64 " S2_T64 ", %[sa], " S2_V64 "\n"
         "  v_or_b32 %[x], %[acc], " S2_TLO "\n"
@@ -168,10 +175,10 @@ __device__ __forceinline__ uint32_t seg2_write_group(uint32_t pairs, uint32_t& l
         "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
         "  v_cndmask_b32 %[acc], %[x], " S2_THI ", vcc\n"
         "  ds_read_b32 %[e], %[t]\n"
-        "  ds_or_b32 %[wa], %[x]\n"
+        S2_OR_STEP
         "  v_lshrrev_b32 %[u], 6, %[c]\n"
         "  v_and_b32 %[wa], -4, %[u]\n"
-        "  s_waitcnt lgkmcnt(1)\n"
+        S2_WAIT_E
         "  v_lshrrev_b32 " S2_VLO ", 8, %[e]\n"
         "  v_lshlrev_b64 " S2_T64 ", %[sb], " S2_V64 "\n"
         "  v_or_b32 %[x], %[acc], " S2_TLO "\n"

@@ -49,13 +49,16 @@ static_assert(sizeof(Seg3Lds) == 160 * 1024, "one workgroup owns the LDS of its 
 #ifdef FDH_S3_DEBUG
 __device__ uint32_t g_s3stat[16];
 __device__ uint32_t g_s3time[4096 * 16];
+__device__ uint32_t g_s3base;  // the 4 096 streams from this one on are sampled (fdh_debug_s3base)
+#define S3SMP (sid - g_s3base < 4096)
+#define S3IDX ((uint32_t)(sid - g_s3base))
 #define S3STAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_s3stat[k], (uint32_t)(v)); } while (0)
-#define S3T(k) do { if (sid < 4096 && (threadIdx.x & 63) == 0) g_s3time[sid * 16 + (k)] = (uint32_t)clock64(); } while (0)
-#define S3N(k, v) do { if (sid < 4096 && (threadIdx.x & 63) == 0) g_s3time[sid * 16 + (k)] = (uint32_t)(v); } while (0)
+#define S3T(k) do { if (S3SMP && (threadIdx.x & 63) == 0) g_s3time[S3IDX * 16 + (k)] = (uint32_t)clock64(); } while (0)
+#define S3N(k, v) do { if (S3SMP && (threadIdx.x & 63) == 0) g_s3time[S3IDX * 16 + (k)] = (uint32_t)(v); } while (0)
 __device__ uint32_t g_s3wtime[4096 * 8];
 #define S3W_DECL uint32_t s3w_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long s3wt_ = clock64()
 #define S3W(k) do { const long long n_ = clock64(); s3w_[k] += (uint32_t)(n_ - s3wt_); s3wt_ = n_; } while (0)
-#define S3W_OUT do { if (sid < 4096 && (threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) g_s3wtime[sid * 8 + k_] = s3w_[k_]; } while (0)
+#define S3W_OUT do { if (S3SMP && (threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) g_s3wtime[S3IDX * 8 + k_] = s3w_[k_]; } while (0)
 #else
 #define S3W_DECL do { } while (0)
 #define S3W(k) do { } while (0)
@@ -107,6 +110,74 @@ __device__ __forceinline__ uint32_t seg3_count_group(uint32_t pairs, uint32_t rb
         : "vcc", "scc", "memory", S2_CLOBBER4);
     return e;
 }
+
+#ifdef FDH_X_DUAL  // timing experiment: a second, independent chain (a copy of the first; its results are dropped) interleaved
+__device__ __forceinline__ uint32_t seg3_count_group_x2(uint32_t pairs, uint32_t rb, uint32_t& lo, uint32_t& hi, uint32_t& c,
+                                                        uint32_t& ra) {
+    uint32_t e, t, nw, e2, t2, nw2, c2 = c, ra2 = ra, lo2 = lo, hi2 = hi, s2lo, s2hi;
+    const uint32_t k256 = 256u, m1f00 = 0x1f00u;
+    asm volatile(
+        "  s_waitcnt lgkmcnt(0)\n"
+        "  v_mov_b32 " S2_WLO ", %[lo]\n"
+        "  v_mov_b32 " S2_WHI ", %[hi]\n"
+        "  v_mov_b32 v126, %[lo2]\n"
+        "  v_mov_b32 v127, %[hi2]\n"
+        "  ds_read_b32 %[nw], %[ra]\n"
+        "  ds_read_b32 %[nw2], %[ra2]\n"
+        "Lpair_%=:\n"
+        "  v_lshrrev_b64 " S2_SHF ", %[c], " S2_WIN "\n"
+        "  v_lshrrev_b64 v[124:125], %[c2], v[126:127]\n"
+        "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
+        "  v_and_b32 %[t2], 0x3ffc, v124\n"
+        "  ds_read_b32 %[e], %[t]\n"
+        "  ds_read_b32 %[e2], %[t2]\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        S2_ADD_BYTE0("%[c]", "%[e]")
+        "  v_lshrrev_b64 " S2_SHF ", %[c], " S2_WIN "\n"
+        "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
+        "  ds_read_b32 %[e], %[t]\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        S2_ADD_BYTE0("%[c2]", "%[e2]")
+        "  v_lshrrev_b64 v[124:125], %[c2], v[126:127]\n"
+        "  v_and_b32 %[t2], 0x3ffc, v124\n"
+        "  ds_read_b32 %[e2], %[t2]\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        S2_ADD_BYTE0("%[c]", "%[e]")
+        "  v_and_b32 %[t], 32, %[c]\n"
+        "  v_cmp_ne_u32 vcc, 0, %[t]\n"
+        "  v_and_b32 %[c], 0xffffffdf, %[c]\n"
+        "  s_sub_u32 %[pairs], %[pairs], 1\n"
+        "  v_cndmask_b32 " S2_WLO ", " S2_WLO ", " S2_WHI ", vcc\n"
+        "  v_cndmask_b32 " S2_WHI ", " S2_WHI ", %[nw], vcc\n"
+        "  v_cndmask_b32 %[t], 0, %[k256], vcc\n"
+        "  v_add_u32 %[t], %[ra], %[t]\n"
+        "  v_and_or_b32 %[ra], %[t], %[m1f00], %[rb]\n"
+        "  ds_read_b32 %[nw], %[ra]\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        S2_ADD_BYTE0("%[c2]", "%[e2]")
+        "  v_and_b32 %[t2], 32, %[c2]\n"
+        "  v_cmp_ne_u32 vcc, 0, %[t2]\n"
+        "  v_and_b32 %[c2], 0xffffffdf, %[c2]\n"
+        "  s_nop 0\n"
+        "  v_cndmask_b32 v126, v126, v127, vcc\n"
+        "  v_cndmask_b32 v127, v127, %[nw2], vcc\n"
+        "  v_cndmask_b32 %[t2], 0, %[k256], vcc\n"
+        "  v_add_u32 %[t2], %[ra2], %[t2]\n"
+        "  v_and_or_b32 %[ra2], %[t2], %[m1f00], %[rb]\n"
+        "  ds_read_b32 %[nw2], %[ra2]\n"
+        "  s_cmp_lg_u32 %[pairs], 0\n"
+        "  s_cbranch_scc1 Lpair_%=\n"
+        "  s_waitcnt lgkmcnt(0)\n"
+        "  v_mov_b32 %[lo], " S2_WLO "\n"
+        "  v_mov_b32 %[hi], " S2_WHI "\n"
+        : [pairs] "+s"(pairs), [lo] "+v"(lo), [hi] "+v"(hi), [c] "+v"(c), [ra] "+v"(ra), [e] "=&v"(e), [t] "=&v"(t),
+          [nw] "=&v"(nw), [e2] "=&v"(e2), [t2] "=&v"(t2), [nw2] "=&v"(nw2), [c2] "+v"(c2), [ra2] "+v"(ra2)
+        : [rb] "v"(rb), [k256] "v"(k256), [m1f00] "s"(m1f00), [lo2] "v"(lo2), [hi2] "v"(hi2)
+        : "vcc", "scc", "memory", S2_CLOBBER8);
+    (void)s2lo; (void)s2hi;
+    return e;
+}
+#endif
 
 // The token at the read position that is no literal step, from the reference-layout table: a run (length
 // symbol, extra bits, the one distance code of the prefix: '0' = distance 1, src/decompress.rs:793-801),
@@ -230,7 +301,11 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
     auto group = [&](uint32_t pairs) __attribute__((always_inline)) {
         uint32_t ra = rb + (((Rw + 2) & 31u) << 8);
         const uint32_t ra0 = ra;
+#ifdef FDH_X_DUAL
+        const uint32_t e = seg3_count_group_x2(pairs, rb, lo, hi, c, ra);
+#else
         const uint32_t e = seg3_count_group(pairs, rb, lo, hi, c, ra);
+#endif
         Rw += ((ra - ra0) >> 8) & 31u;
         return e;
     };
@@ -373,9 +448,15 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
             c += chain << 6;
             bl += chain >= kS2LongRun ? chain / 16 - 1 : 0u;
             // on to the next chain only where the lane sits on a run token again (anything else: back to the look-ups);
-            // the interval that starts behind this chain is then a chain and nothing else, in front of it zeros: marked
-            const S3Tok t = s3_token(canon, window30());
-            const bool again = more && chain != 0 && !stopped && !fault && pos < target && t.run != 0 && !t.bad;
+            // the interval that starts behind this chain is then a chain and nothing else, in front of it zeros: marked.
+            // (Only a chain that was cut off -- `go` still set: its last token was a 258-byte one -- is looked behind: a
+            //  run token behind any other chain, which the reference's encoder never writes, parks the lane at its next
+            //  look-up and is taken then.)
+            bool again = false;
+            if (__any(go)) {
+                const S3Tok t = s3_token(canon, window30());
+                again = go && more && chain != 0 && !stopped && !fault && pos < target && t.run != 0 && !t.bad;
+            }
             cut(more && chain != 0, again ? pure_flag : 0u);
             more = again;
             if (__any(more)) refill();
@@ -424,10 +505,10 @@ __device__ __forceinline__ bool seg3_plan(const SegArgs& a, const uint32_t* lit,
         S3T(4);
         S3N(10, dbg_periods);
         S3N(11, dbg_special);
-        // groups, pairs
-    #pragma unroll
-        for (int stage = 0; stage < 2; stage++) {
-            const uint32_t pairs = stage == 0 ? kS2Pairs : 1u;
+        // half a period, a quarter, ... a pair: a lane takes each size at most once on its way to the target (and again
+        // behind a run chain), so the lanes are through in a handful of trips (rounds 5: groups of 8, then pairs: ~11)
+    #pragma unroll 1
+        for (uint32_t pairs = kS3PeriodPairs / 2; pairs != 0; pairs >>= 1) {
             const uint32_t bits = 2 * pairs * kLitBits;
             for (;;) {
                 const bool act = need && !stopped && !fault && pos + bits <= target;
@@ -736,6 +817,9 @@ __device__ __forceinline__ bool seg3_write(const SegArgs& a, const uint32_t* lit
         //      per trip, both read before the first is used ----
         auto piece = [&](const uint4 q, const uint32_t v) __attribute__((always_inline)) {
             *reinterpret_cast<uint4*>(op + v) = q;
+#ifdef FDH_X_NO_ADLER  // timing experiment (wrong checksum)
+            return;
+#endif
             uint32_t sum = bytesum4(q.x);
             sum = __builtin_amdgcn_sad_u8(q.y, 0u, sum);
             sum = __builtin_amdgcn_sad_u8(q.z, 0u, sum);

@@ -12,6 +12,10 @@ __device__ uint32_t g_s3seq[4096 * 64];
 // its own counting pass; what it does not take is listed for the interval kernel.
 __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArgs a) {
     __shared__ Seg3Lds lds;
+#ifdef FDH_S3_DEBUG
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * kS2Waves + threadIdx.x / kWave < 4096)
+        g_s3seq[(blockIdx.x * kS2Waves + threadIdx.x / kWave) * 64 + 63] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     if (lds_offset(lds.lit) != 0) __builtin_trap();
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.canon_lit2);
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg3_kernel(SegArg
 #ifdef FDH_S3_DEBUG
     const uint32_t wv_ = blockIdx.x * kS2Waves + threadIdx.x / kWave;
     uint32_t nseq_ = 0;
-    if (lane == 0 && wv_ < 4096) g_s3seq[wv_ * 64 + 63] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && wv_ < 4096) g_s3seq[wv_ * 64 + 62] = (uint32_t)__builtin_amdgcn_s_memrealtime();  // tables staged
 #endif
     for (;;) {
         if (cur == end) {
@@ -82,6 +86,9 @@ extern "C" int fdh_debug_s3time(uint32_t* host) {
 #endif
     if (hipMemcpyFromSymbol(host + 4096 * 16 + 16 + 4096 * 16, HIP_SYMBOL(fdh::g_s3wtime), 4096 * 8 * 4) != hipSuccess) return 5;
     return 0;
+}
+extern "C" int fdh_debug_s3base(uint32_t base) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_s3base), &base, 4) == hipSuccess ? 0 : 1;
 }
 extern "C" int fdh_debug_s3seq(uint32_t* host) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;

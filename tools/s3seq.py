@@ -40,6 +40,8 @@ cnt = w[:, 0]
 ends = np.array([(w[i, 2 * cnt[i]] - t0) / 100.0 if cnt[i] else start[i] for i in range(4096)])
 print("wavefronts: start spread %.1f us (p50 %.1f, p99 %.1f); streams per wavefront min %d mean %.1f max %d" %
       (start.max(), np.median(start), np.percentile(start, 99), cnt.min(), cnt.mean(), cnt.max()))
+staged = (w[:, 62] - w[:, 63]) / 100.0
+print("tables staged after %.1f us (p50; p99 %.1f)" % (np.median(staged), np.percentile(staged, 99)))
 print("kernel: last wavefront done at %.1f us; mean done %.1f; idle at the end: mean %.1f us, p10 %.1f, p90 %.1f" %
       (ends.max(), ends.mean(), (ends.max() - ends).mean(), np.percentile(ends.max() - ends, 10), np.percentile(ends.max() - ends, 90)))
 mean_len = cl.mean()

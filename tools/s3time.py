@@ -24,10 +24,12 @@ out = torch.empty(n * L, dtype=torch.uint8, device=dev)
 ol = torch.empty(n, dtype=torch.int32, device=dev)
 st = torch.empty(n, dtype=torch.int32, device=dev)
 ad = torch.empty(n, dtype=torch.int32, device=dev)
+Lc = _lib.lib()
+base = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # sample the 4 096 streams from this one on (a multiple of 16)
+assert Lc.fdh_debug_s3base(C.c_uint32(base)) == 0
 for _ in range(3):
     fd.inflate_batch(comp, c_off, out, r_off, ol, st, ad, flags=0)
 torch.cuda.synchronize()
-Lc = _lib.lib()
 buf = np.zeros(4096 * 16 + 16 + 4096 * 16 + 4096 * 8, dtype=np.uint32)
 assert Lc.fdh_debug_s3time(buf.ctypes.data_as(C.c_void_p)) == 0
 t = buf[:4096 * 16].reshape(4096, 16).astype(np.int64)
@@ -65,6 +67,8 @@ done = [i for i in range(min(n, 4096)) if t[i, 8] != 0]
 report("noisy", [i for i in done if i % 16 not in (7, 15)])
 report("half-zero", [i for i in done if i % 16 == 7])
 report("all-zero", [i for i in done if i % 16 == 15])
+if os.environ.get("S3DUMP"):
+    np.save(os.environ["S3DUMP"], t)
 print("stat:", buf[4096 * 16:4096 * 16 + 4])
 if os.environ.get("S3RAW"):
     for i in done[:6]:
