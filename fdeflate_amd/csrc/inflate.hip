@@ -685,11 +685,14 @@ __global__ __launch_bounds__(kSegWaves* kWave, 4) void inflate_segments_kernel(S
 // (its first eight bytes) never get to the interval kernel: they go straight onto the list of the kernels
 // behind it -- handing 65 536 of them out one atomic at a time only to pass them on cost 0.8 ms.
 // counters: [0..3] the streams of each class (SegOrder), zeroed.
-__global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, const uint64_t* in_off, uint32_t n, uint32_t* order,
-                                                           uint32_t* counters, const uint32_t* canon_hdr, uint32_t* status,
-                                                           uint32_t pending, uint32_t* list2, uint32_t second) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & (kWave - 1);
+__global__ __launch_bounds__(1024) void stream_order_kernel(const uint8_t* in, const uint64_t* in_off, uint32_t n, uint32_t* order,
+                                                            uint32_t* counters, const uint32_t* canon_hdr, uint32_t* status,
+                                                            uint32_t pending, uint32_t* list2, uint32_t second) {
+    // (round 6) one atomic per class and workgroup of 16 wavefronts: a wavefront each, 1 024 of them after the
+    // one counter most streams of a batch fall into, serialised to ~20 us in front of the first decode kernel
+    __shared__ uint32_t s_cnt[16][5], s_base[16][5];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint64_t mean = (in_off[n] - in_off[0]) / n, thr = mean / 2;
     const bool valid = i < n;
     const uint64_t len = valid ? in_off[i + 1] - in_off[i] : 0;
@@ -707,26 +710,35 @@ __global__ __launch_bounds__(256) void stream_order_kernel(const uint8_t* in, co
     // (the other streams' list is walked from the front by persistent wavefronts too: the long ones are listed by
     //  the first launch of this kernel, the short ones behind them by a second launch, `second`)
     const bool other = valid && !canon && ((len >= thr) != (second != 0));
-    const uint32_t cls = seg_order_class(len, mean);
+    // class 0..3: the canonical streams by length (SegOrder); class 4: the other list
+    const uint32_t cls = other ? 4u : ((canon && !second) ? seg_order_class(len, mean) : 5u);
     const uint64_t below = (1ull << lane) - 1;
+    uint32_t rank = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {  // the canonical streams by class: SegOrder
-        const bool mine = canon && !second && cls == k;
-        const uint64_t m = __ballot(mine);
-        if (m == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&counters[k], (uint32_t)__popcll(m));
-        base = __shfl(base, 0);
-        const uint32_t r = base + (uint32_t)__popcll(m & below);
-        if (mine) order[k == 0 ? r : (k == 1 ? n - 1 - r : (k == 2 ? n + r : 2 * n - 1 - r))] = i;
+    for (uint32_t k = 0; k < 5; k++) {
+        const uint64_t m = __ballot(cls == k);
+        if (cls == k) rank = (uint32_t)__popcll(m & below);
+        if (lane == 0) s_cnt[wave][k] = (uint32_t)__popcll(m);
     }
-    const uint64_t mo = __ballot(other);
-    uint32_t base_o = 0;
-    if (lane == 0 && mo) base_o = atomicAdd(&list2[0], (uint32_t)__popcll(mo));
-    base_o = __shfl(base_o, 0);
-    if (other) {
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const uint32_t k = threadIdx.x;
+        uint32_t total = 0;
+        for (int w = 0; w < 16; w++) {
+            s_base[w][k] = total;
+            total += s_cnt[w][k];
+        }
+        uint32_t base = 0;
+        if (total) base = atomicAdd(k < 4 ? &counters[k] : &list2[0], total);
+        for (int w = 0; w < 16; w++) s_base[w][k] += base;
+    }
+    __syncthreads();
+    if (cls < 4) {
+        const uint32_t r = s_base[wave][cls] + rank;
+        order[cls == 0 ? r : (cls == 1 ? n - 1 - r : (cls == 2 ? n + r : 2 * n - 1 - r))] = i;
+    } else if (cls == 4) {
         status[i] = pending;
-        list2[4 + base_o + (uint32_t)__popcll(mo & below)] = i;
+        list2[4 + s_base[wave][4] + rank] = i;
     }
 }
 
@@ -1176,7 +1188,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 uint32_t* order = list + list2_at + (n + 4);
                 uint32_t* counters = list + (n + 4);
                 for (uint32_t second = 0; second < 2; second++)
-                    hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, in_off, (uint32_t)n, order,
+                    hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, stream, in, in_off, (uint32_t)n, order,
                                        counters, canon->hdr, status, fdh::kPending, sa.list2, second);
                 e = hipGetLastError();
                 if (e != hipSuccess) {
@@ -1201,7 +1213,24 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                     b.lz_ck = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes);
                     b.resume = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes);
                     hipLaunchKernelGGL(fdh::inflate_lz_kernel, dim3(lblocks), dim3(fdh::kWave), 0, side, b);
-                    forked = hipGetLastError() == hipSuccess && hipEventRecord(ev_join, side) == hipSuccess;
+                    forked = hipGetLastError() == hipSuccess;
+                    // (round 6) what the LZ-window kernel leaves depends on nothing the canonical kernels do: its two
+                    // exact kernels follow it on the side stream, off the chain of launches behind the landing decoder
+                    // (a launch that finds its list empty still costs ~10 us of that chain)
+                    fdh::InflateBatchArgs g = a;
+                    g.only_pending = 1;
+                    g.resume = b.resume;
+                    g.list = list + list5_at;
+                    const unsigned gblocks5 = (unsigned)std::min<uint64_t>(n, 4096);
+                    if (forked && !(flags & 0x200u)) {
+                        hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3(gblocks5), dim3(fdh::kWave), 0, side, g);
+                        forked = hipGetLastError() == hipSuccess;
+                    }
+                    if (forked) {
+                        hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3(gblocks5), dim3(fdh::kWave), 0, side, g);
+                        forked = hipGetLastError() == hipSuccess;
+                    }
+                    forked = forked && hipEventRecord(ev_join, side) == hipSuccess;
                 }
                 if (ev_fork) (void)hipEventDestroy(ev_fork);
                 if (!forked) {  // (nothing has been started on the other stream, or it cannot be joined: give up cleanly)
@@ -1263,8 +1292,8 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 (void)hipEventDestroy(ev_join);
                 if (e == hipSuccess) e = ej;
                 const unsigned gblocks = (unsigned)std::min<uint64_t>(n, 4096);
-                for (int which = 0; which < 2 && e == hipSuccess; which++) {
-                    a.list = which == 0 ? list + list4_at : list + list5_at;
+                if (e == hipSuccess) {  // (the other list's exact kernels ran on the side stream, behind the LZ-window kernel)
+                    a.list = list + list4_at;
                     if (!(flags & 0x200u)) {
                         hipLaunchKernelGGL(fdh::inflate_general_fast_kernel, dim3(gblocks), dim3(fdh::kWave), 0, stream, a);
                         e = hipGetLastError();

@@ -111,74 +111,6 @@ __device__ __forceinline__ uint32_t seg3_count_group(uint32_t pairs, uint32_t rb
     return e;
 }
 
-#ifdef FDH_X_DUAL  // timing experiment: a second, independent chain (a copy of the first; its results are dropped) interleaved
-__device__ __forceinline__ uint32_t seg3_count_group_x2(uint32_t pairs, uint32_t rb, uint32_t& lo, uint32_t& hi, uint32_t& c,
-                                                        uint32_t& ra) {
-    uint32_t e, t, nw, e2, t2, nw2, c2 = c, ra2 = ra, lo2 = lo, hi2 = hi, s2lo, s2hi;
-    const uint32_t k256 = 256u, m1f00 = 0x1f00u;
-    asm volatile(
-        "  s_waitcnt lgkmcnt(0)\n"
-        "  v_mov_b32 " S2_WLO ", %[lo]\n"
-        "  v_mov_b32 " S2_WHI ", %[hi]\n"
-        "  v_mov_b32 v126, %[lo2]\n"
-        "  v_mov_b32 v127, %[hi2]\n"
-        "  ds_read_b32 %[nw], %[ra]\n"
-        "  ds_read_b32 %[nw2], %[ra2]\n"
-        "Lpair_%=:\n"
-        "  v_lshrrev_b64 " S2_SHF ", %[c], " S2_WIN "\n"
-        "  v_lshrrev_b64 v[124:125], %[c2], v[126:127]\n"
-        "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
-        "  v_and_b32 %[t2], 0x3ffc, v124\n"
-        "  ds_read_b32 %[e], %[t]\n"
-        "  ds_read_b32 %[e2], %[t2]\n"
-        "  s_waitcnt lgkmcnt(1)\n"
-        S2_ADD_BYTE0("%[c]", "%[e]")
-        "  v_lshrrev_b64 " S2_SHF ", %[c], " S2_WIN "\n"
-        "  v_and_b32 %[t], 0x3ffc, " S2_SH0 "\n"
-        "  ds_read_b32 %[e], %[t]\n"
-        "  s_waitcnt lgkmcnt(1)\n"
-        S2_ADD_BYTE0("%[c2]", "%[e2]")
-        "  v_lshrrev_b64 v[124:125], %[c2], v[126:127]\n"
-        "  v_and_b32 %[t2], 0x3ffc, v124\n"
-        "  ds_read_b32 %[e2], %[t2]\n"
-        "  s_waitcnt lgkmcnt(1)\n"
-        S2_ADD_BYTE0("%[c]", "%[e]")
-        "  v_and_b32 %[t], 32, %[c]\n"
-        "  v_cmp_ne_u32 vcc, 0, %[t]\n"
-        "  v_and_b32 %[c], 0xffffffdf, %[c]\n"
-        "  s_sub_u32 %[pairs], %[pairs], 1\n"
-        "  v_cndmask_b32 " S2_WLO ", " S2_WLO ", " S2_WHI ", vcc\n"
-        "  v_cndmask_b32 " S2_WHI ", " S2_WHI ", %[nw], vcc\n"
-        "  v_cndmask_b32 %[t], 0, %[k256], vcc\n"
-        "  v_add_u32 %[t], %[ra], %[t]\n"
-        "  v_and_or_b32 %[ra], %[t], %[m1f00], %[rb]\n"
-        "  ds_read_b32 %[nw], %[ra]\n"
-        "  s_waitcnt lgkmcnt(1)\n"
-        S2_ADD_BYTE0("%[c2]", "%[e2]")
-        "  v_and_b32 %[t2], 32, %[c2]\n"
-        "  v_cmp_ne_u32 vcc, 0, %[t2]\n"
-        "  v_and_b32 %[c2], 0xffffffdf, %[c2]\n"
-        "  s_nop 0\n"
-        "  v_cndmask_b32 v126, v126, v127, vcc\n"
-        "  v_cndmask_b32 v127, v127, %[nw2], vcc\n"
-        "  v_cndmask_b32 %[t2], 0, %[k256], vcc\n"
-        "  v_add_u32 %[t2], %[ra2], %[t2]\n"
-        "  v_and_or_b32 %[ra2], %[t2], %[m1f00], %[rb]\n"
-        "  ds_read_b32 %[nw2], %[ra2]\n"
-        "  s_cmp_lg_u32 %[pairs], 0\n"
-        "  s_cbranch_scc1 Lpair_%=\n"
-        "  s_waitcnt lgkmcnt(0)\n"
-        "  v_mov_b32 %[lo], " S2_WLO "\n"
-        "  v_mov_b32 %[hi], " S2_WHI "\n"
-        : [pairs] "+s"(pairs), [lo] "+v"(lo), [hi] "+v"(hi), [c] "+v"(c), [ra] "+v"(ra), [e] "=&v"(e), [t] "=&v"(t),
-          [nw] "=&v"(nw), [e2] "=&v"(e2), [t2] "=&v"(t2), [nw2] "=&v"(nw2), [c2] "+v"(c2), [ra2] "+v"(ra2)
-        : [rb] "v"(rb), [k256] "v"(k256), [m1f00] "s"(m1f00), [lo2] "v"(lo2), [hi2] "v"(hi2)
-        : "vcc", "scc", "memory", S2_CLOBBER8);
-    (void)s2lo; (void)s2hi;
-    return e;
-}
-#endif
-
 // The token at the read position that is no literal step, from the reference-layout table: a run (length
 // symbol, extra bits, the one distance code of the prefix: '0' = distance 1, src/decompress.rs:793-801),
 // the end-of-block code, or nothing valid.  `w` = 30 stream bits from the token on.
