@@ -69,11 +69,13 @@ using BitRing = BitRingT<kEncRingDw>;
 
 struct EncLds {
     uint32_t tab[288];
+    uint32_t tail[260];  // (round 6) run_tail of every r < 258: bits | nbits << 24 -- a look-up, not ~30 instructions per tile
     uint32_t ring[kEncWaves][kEncRingDw];
 };
 
 struct Encoder : BitRing {
     const uint32_t* tab;
+    const uint32_t* tail;  // run_tail as a table (EncLds::tail)
 
     // write_run (ultrafast.rs:45-67) for one run, emitted by the whole wavefront (slow path
     // and the end-of-data run).
@@ -90,9 +92,8 @@ struct Encoder : BitRing {
             qbits += (uint64_t)m * rep_n;
             nrep -= m;
         }
-        uint32_t tb, tn;
-        run_tail(r, tb, tn);
-        emit_uniform(tb, tn);
+        const uint32_t te = tail[r];
+        emit_uniform(te & 0xFFFFFFu, te >> 24);
     }
 
     // tail of a run: r = (run - 1) % 258 more zeros (ultrafast.rs:54-64)
@@ -262,6 +263,16 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
     for (int i = threadIdx.x; i < 288; i += kEncWaves * kWave) lds.tab[i] = i < 286 ? kUfTables.sym[i] : 0;
     for (int i = lane; i < kEncRingDw; i += kWave) lds.ring[wid][i] = 0;
     __syncthreads();
+    {   // the tails of the runs, from the code table just staged
+        Encoder e0;
+        e0.tab = lds.tab;
+        for (int i = threadIdx.x; i < 260; i += kEncWaves * kWave) {
+            uint32_t tb = 0, tn = 0;
+            if (i < 258) e0.run_tail((uint32_t)i, tb, tn);
+            lds.tail[i] = tb | (tn << 24);
+        }
+    }
+    __syncthreads();
     const uint64_t sid = (uint64_t)blockIdx.x * kEncWaves + wid;
     if (sid >= a.n) return;
 
@@ -293,6 +304,7 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
     Encoder enc;
     enc.ring = lds.ring[wid];
     enc.tab = lds.tab;
+    enc.tail = lds.tail;
     enc.lane = lane;
     enc.gmis = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15);
     enc.out_al = out - enc.gmis;
@@ -394,13 +406,15 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
         }
         // ---- run closed by this chunk (write_run, ultrafast.rs:45-67) ----
         uint32_t nrep = 0, tail_bits = 0, tail_n = 0, run_n = 0;
-        if (pend) {
-            uint32_t run = P + tzb - 1;  // after the leading literal 0
-            nrep = run / 258;
-            enc.run_tail(run % 258, tail_bits, tail_n);
-            run_n = 2 + nrep * ((lds.tab[285] >> 16) + 1) + tail_n;
-        }
         const uint32_t e285 = lds.tab[285];
+        {   // (all lanes: a table look-up and a handful of selects -- no branch around ~30 instructions)
+            const uint32_t run = pend ? P + tzb - 1 : 0u;  // after the leading literal 0
+            nrep = run / 258;
+            const uint32_t te = lds.tail[run - 258 * nrep];
+            tail_bits = pend ? te & 0xFFFFFFu : 0u;
+            tail_n = pend ? te >> 24 : 0u;
+            run_n = pend ? 2 + nrep * ((e285 >> 16) + 1) + tail_n : 0u;
+        }
         const uint32_t lane_bits = run_n + lit_n;
         uint32_t total;
         const uint32_t off = wave_excl_scan_u32(lane_bits, lane, total);
