@@ -162,6 +162,7 @@ struct fdh_decompressor {
     size_t res_out = 0;
     uint32_t res_adler = 0, res_step = 0;
     uint32_t lz_unknown = 0;  // attempts in a row whose resume point came without its step state (below)
+    bool stalled = false;     // the last attempt moved neither the resume point nor the decoded prefix (the input bound yields then)
     uint64_t decoded = 0;     // output bytes decoded by all attempts together (introspection: N for a stream of N bytes
                               // that is never decoded twice)
     size_t peak_bytes = 0;    // the most device memory the three buffers have held together
@@ -239,6 +240,11 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
         const size_t unread = d->in_total - std::min<size_t>(d->in_total, d->res_valid ? (size_t)(d->res_bit >> 3) : 0);
         const size_t bound = std::min<size_t>(std::max(kInCap, room), 32u << 20);
         accept = unread >= bound ? 0 : std::min(input_len, bound - unread);
+        // (round 6) The bound is there so that the unread input goes DOWN before more is taken; an attempt that moved
+        // nothing -- no point came back, or one without its step state even from the tile decoders, and every decoded
+        // byte had been delivered -- would be repeated on the same bytes for ever if the input stayed refused: the call
+        // would return (0, 0), not done, no error, again and again.  More input is what can move it: it is taken.
+        if (accept == 0 && input_len != 0 && d->stalled) accept = std::min(input_len, bound);
     }
     if (accept) {
         const size_t have = d->in_total - d->tail_base;
@@ -304,6 +310,7 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     if (!attempt) return FDH_SUCCESS;  // (nothing of the prefix is left over here: that state is output-limited)
 
     const bool go_on = !no_resume && d->res_valid;
+    const uint64_t res_bit_before = d->res_valid ? d->res_bit : 0;
     static const bool no_trim = std::getenv("FDH_STREAM_NO_TRIM") != nullptr;  // (A/B: resume points, but nothing is dropped)
     // ---- what the resume point no longer needs goes: output in front of its history (and of what the caller has not
     //      taken yet), input in front of its bit ----
@@ -468,6 +475,7 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     const uint32_t st = host_res[1];
     d->tried = true;
     d->attempted_in = d->in_total;
+    d->stalled = false;
     size_t have = 0;  // valid prefix of the decoded stream (a stream position)
     if (st == FDH_STREAM_OK || st == FDH_WRONG_CHECKSUM || st == FDH_OUTPUT_TOO_LARGE || st == FDH_INSUFFICIENT_INPUT) {
         have = std::min<size_t>(d->out_base + host_res[0], cap);
@@ -475,6 +483,8 @@ int fdh_decompressor_read(fdh_decompressor* d, const uint8_t* input, size_t inpu
     d->ahead_have = std::max(have, d->delivered);
     d->ahead_in = d->in_total;
     d->ahead_st = st;
+    d->stalled = (st == FDH_INSUFFICIENT_INPUT || st == FDH_OUTPUT_TOO_LARGE) && d->ahead_have == d->delivered &&
+                 (!d->res_valid || d->res_bit == res_bit_before);
     return deliver(std::min(room, d->ahead_have - d->delivered));
 #undef HIP_TRY
 }

@@ -1277,3 +1277,27 @@ def test_png_filter_fused_into_the_ultrafast_encoder():
             assert got == want, (rb, bpp, i, len(got), len(want))
             assert zlib.decompress(got) == filt
             assert np.all(h[ooff[i] + oll[i]:ooff[i + 1]] == 0xEE)   # nothing behind the stream
+
+
+def test_bench_through_the_distributed_path_in_a_fresh_process():
+    """`bench.py --gpus 1 --force-dist` as a child process: the launcher, `init_process_group("nccl")`, the metadata
+    all-gather inside the step, the barriers and the max over ranks -- the code path `--gpus 8` takes, with one rank --
+    on this GPU, and one JSON line with `n_gpus`, the roofline block and a sane value at its end."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--streams", "4096",
+                        "--steps", "2", "--warmup", "1", "--no-also", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "GB/s" and d["scaling"] == "weak"
+    assert d["value"] > 50 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
