@@ -266,7 +266,13 @@ int fdh_inflate_png_batch(const uint8_t *in, const uint64_t *in_off, uint8_t *fi
  *      and on every EMPTY input).  A caller must therefore conclude "truncated" (the reference's InsufficientInput,
  *      src/decompress.rs:1135-1136) only after a read with empty input has produced nothing and
  *      is_done is still false -- which is what the reference's own harness and the png crate do at
- *      the end of their input anyway.
+ *      the end of their input anyway.  (tests/test_gpu_streaming.py,
+ *      test_reference_bounded_loop_over_the_streaming_object: the loop of the reference's own
+ *      decompress_to_vec_bounded, src/decompress.rs:1111-1144, with that one flush added, over streams of more
+ *      than 256 KiB whole and in 40 000-byte pieces.)
+ *   3. (round 6) The bound of 1. never holds a stream up: an attempt that moved nothing -- no new resume point, no new
+ *      byte -- is followed by a call that takes input again, bound or no bound, because more input is the only
+ *      thing that can move it.  A sequence of calls with input left therefore never returns (0, 0) for ever.
  * Device memory (round 5): like the reference, which keeps its tables and needs the last 32 KiB of the caller's
  * buffer (src/decompress.rs:96-113, 1067-1070), the object keeps what its resume point needs and no more -- the
  * unread input, a copy of the current block's header, 32 KiB of history and the window with what has been decoded

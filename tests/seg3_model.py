@@ -90,7 +90,8 @@ class Stream:
 
 LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
 LEN_EXTRA = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
-REPEAT = 8         # run tokens followed in one chain
+REPEAT = 8         # run tokens followed in one chain (the general writer's streams)
+REPEAT_LEAN = 64   # ... of a stream the lean writer takes (round 6: its chains never enter the output image, however long)
 
 
 def special(st, pos):
@@ -131,10 +132,10 @@ def guess(st, start, leave):
 
 
 def chain(st, pos, bound):
-    """The run chain at `pos`: the first run token and, while they are 258 bytes long, up to REPEAT - 1
+    """The run chain at `pos`: the first run token and, while they are 258 bytes long, up to st.repeat - 1
     more, none of them reaching past `bound` (None: no bound).  Returns (bytes, end position) or None."""
     total = 0
-    for rep in range(REPEAT):
+    for rep in range(getattr(st, "repeat", REPEAT)):
         kind, bits, run = special(st, pos)
         if kind != "run":
             if rep == 0:
@@ -223,10 +224,12 @@ def count_to(st, pos, target, stats):
     return cnt, pos, ck, True
 
 
-def plan(data, lengths, canon_bits, nseg=64):
+def plan(data, lengths, canon_bits, nseg=64, repeat=REPEAT):
     """The counting pass of one stream.  Returns (total bytes, per-lane results, stats) or None when a
-    lane did not land (the kernel then counts that lane's neighbour again / leaves the stream)."""
+    lane did not land (the kernel then counts that lane's neighbour again / leaves the stream).
+    `repeat`: the run tokens a chain may merge (REPEAT, or REPEAT_LEAN for a stream the lean writer takes)."""
     st = Stream(data, lengths)
+    st.repeat = repeat
     data_bits = st.nbits - canon_bits
     seg = (data_bits + nseg - 1) // nseg
     x0 = [canon_bits] + [guess(st, canon_bits + l * seg, canon_bits + l * seg + WINDOW) for l in range(1, nseg)]

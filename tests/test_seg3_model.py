@@ -18,10 +18,12 @@ LENGTHS = (list(G["HUFFMAN_LENGTHS"]) + [0, 0])[:288]
 CANON_BITS = 53 * 8 + 5  # reference src/compress/ultrafast.rs:82-88: 53 bytes and 5 bits of prefix
 
 
-def _check(raw):
+def _check(raw, repeat=m.REPEAT):
     comp = ob.compress_ultra_fast(raw)
     assert zlib.decompress(comp) == raw
-    total, lanes, stats = m.plan(comp, LENGTHS, CANON_BITS)
+    # (as the kernel: no segment shorter than 1 024 bits -- a short stream uses fewer lanes)
+    nseg = min(64, max(1, (len(comp) * 8 - CANON_BITS) // 1024))
+    total, lanes, stats = m.plan(comp, LENGTHS, CANON_BITS, nseg=nseg, repeat=repeat)
     assert total == len(raw), stats
     # every lane lands on its neighbour's start; the intervals of a lane are at most METER steps long and
     # their byte counts add up
@@ -37,6 +39,18 @@ def test_bench_streams_land():
     for i in (1, 2, 7, 9):  # noisy rows; every other row zero (long run chains)
         stats = _check(synth.gen_stream_np(i).tobytes())
         assert stats["fail"] == 0
+
+
+def test_long_chains_of_the_lean_writer():
+    """Round 6: a stream the lean writer takes merges up to 64 run tokens into a chain (an all-zero 64 KiB buffer is
+    four chains, not 32): the same bytes, the same landings, fewer intervals."""
+    for i in (7, 15):  # every other row zero; all zero
+        raw = synth.gen_stream_np(i).tobytes()
+        a = _check(raw)
+        b = _check(raw, repeat=m.REPEAT_LEAN)
+        assert b["fail"] == 0 and b["chains"] <= a["chains"]
+    z = _check(bytes(65536), repeat=m.REPEAT_LEAN)
+    assert z["chains"] <= 6, z
 
 
 def test_other_models_and_lengths_land():
