@@ -22,6 +22,10 @@
 //     per-lane ring levels, predicates and pending chunks at every 16 look-ups.
 //   * a lane that meets a token that is no literal marks time to the end of its period (a zero entry of
 //     the step table changes nothing) and all such lanes take their run chains together.
+// Round 6: a stream the lean writer (seg3_write) will take -- known at set-up -- merges up to kS3Repeat run tokens into
+// a chain (five 258-byte tokens per step in a flat stretch) and marks the intervals that are a chain behind a chain
+// (kS3PureFlag): such chains never enter the writer's image, whose zeros they would only leave as they are; the
+// writer stores them straight to the slot.  The tail of a chain is taken in halves (8, 4, 2, 1 pairs of look-ups).
 #pragma once
 #include "inflate_seg2.h"
 
