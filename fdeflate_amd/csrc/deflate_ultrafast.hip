@@ -325,8 +325,25 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
     // ---- Adler-32 of the input (ultrafast.rs:95), per-lane partial sums ----
     // A = 1 + sum d_i ; B = len + sum (len - i) d_i  (mod 65521)
     uint64_t acc_a = 0, acc_b = 0;
+    // (round 6) per tile only 32-bit sums: the weight of chunk c's bytes is (len - 8 c) = (len - 8 (f0 + lane)) - 512 k for
+    // the k-th tile behind the last fold at tile base f0, so  sum (len - 8 c) s_k - u_k  =  (len - 8 (f0 + lane)) S1 -
+    // 512 S2 - U  with S1 = sum s_k, S2 = sum k s_k, U = sum u_k -- one 64-bit multiply-add per 256 tiles, not per tile
+    uint32_t ad_s1 = 0, ad_s2 = 0, ad_u = 0, ad_k = 0, ad_f0 = 0;
+    auto adler_fold = [&]() __attribute__((always_inline)) {
+        acc_a += ad_s1;
+        acc_b += (uint64_t)((uint32_t)len - 8u * (ad_f0 + (uint32_t)lane)) * ad_s1 - 512ull * ad_s2 - ad_u;
+        acc_a %= kAdlerMod;
+        acc_b %= kAdlerMod;
+        ad_s1 = ad_s2 = ad_u = ad_k = 0;
+    };
 
-    const uint64_t nchunks = len / 8;
+    // (round 6: chunk numbers are 32-bit -- a buffer of 4 GiB or more cannot be encoded into a slot whose length comes
+    // back in 32 bits anyway: out_len = 0xFFFFFFFF, as for a slot that is too small)
+    if (len >> 32) {
+        if (lane == 0) a.out_len[sid] = 0xFFFFFFFFu;
+        return;
+    }
+    const uint32_t nchunks = (uint32_t)(len / 8);
     uint32_t carry = 0;  // pending run (zero bytes) entering the tile; may exceed 2^32? len < 2^32 assumed below
     // the chunk of the NEXT tile is requested while this one is encoded (the loads are the only
     // global-memory latency of the loop)
@@ -334,38 +351,39 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
     // and drop it): behind a load in a branch the compiler cannot know how many loads are in flight
     // and waits for all of them -- the prefetch it had just issued included -- at the join, which
     // put a full trip to memory into every tile.
-    const uint64_t last_chunk = nchunks ? nchunks - 1 : 0;
+    const uint32_t last_chunk = nchunks ? nchunks - 1 : 0;
     uint64_t x_next = 0;
     PngSource::Req req{0, 0, 0, 0, 0, 0, true};  // PNG: the chunk of the tile after next, requested
     if (PNG) {
-        if (nchunks) x_next = png.finish(png.request(min((uint64_t)lane, last_chunk) * 8), (uint64_t)lane < nchunks);
-        if (nchunks) req = png.request(min((uint64_t)lane + kWave, last_chunk) * 8);
+        if (nchunks) x_next = png.finish(png.request((uint64_t)min((uint32_t)lane, last_chunk) * 8), (uint32_t)lane < nchunks);
+        if (nchunks) req = png.request((uint64_t)min((uint32_t)lane + kWave, last_chunk) * 8);
     } else if (nchunks) {
-        x_next = *reinterpret_cast<const uint64_t*>(in + min((uint64_t)lane, last_chunk) * 8);  // HW handles misalignment
+        x_next = *reinterpret_cast<const uint64_t*>(in + (uint64_t)min((uint32_t)lane, last_chunk) * 8);  // HW handles misalignment
     }
-    if ((uint64_t)lane >= nchunks) x_next = 0;
-    for (uint64_t t0 = 0; t0 < nchunks; t0 += kWave) {
+    if ((uint32_t)lane >= nchunks) x_next = 0;
+    for (uint32_t t0 = 0; t0 < nchunks; t0 += kWave) {
         // (the ring's counters are uniform; said so, their 64-bit arithmetic goes to the scalar unit)
         enc.qbits = uni64(enc.qbits);
         enc.qflushed = uni64(enc.qflushed);
-        const uint64_t c = t0 + lane;
+        const uint32_t c = t0 + (uint32_t)lane;
         const bool valid = c < nchunks;
         const uint64_t x = x_next;
         if (PNG) {
             x_next = png.finish(req, c + kWave < nchunks);             // tile t + 1: requested a tile ago
-            req = png.request(min(c + 2 * kWave, last_chunk) * 8);     // tile t + 2
+            req = png.request((uint64_t)min(c + 2 * kWave, last_chunk) * 8);     // tile t + 2
         } else {
-            x_next = *reinterpret_cast<const uint64_t*>(in + min(c + kWave, last_chunk) * 8);
+            x_next = *reinterpret_cast<const uint64_t*>(in + (uint64_t)min(c + kWave, last_chunk) * 8);
         }
         if (c + kWave >= nchunks) x_next = 0;
-        const uint32_t nvalid = (uint32_t)min((uint64_t)kWave, nchunks - t0);
+        const uint32_t nvalid = min((uint32_t)kWave, nchunks - t0);
         {   // adler partials: weight of byte j of this chunk is len - (c*8 + j)
-            uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
-            uint32_t s = bytesum4(xl) + bytesum4(xh);
-            uint32_t u = bytedot4(xl, 0x03020100u, 0);
-            u = bytedot4(xh, 0x07060504u, u);
-            acc_a += s;
-            acc_b += (uint64_t)(len - c * 8) * s - u;  // valid lanes only contribute (x = 0 otherwise)
+            const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+            const uint32_t s = bytesum4(xl) + bytesum4(xh);  // (x = 0 in the lanes past the end: they contribute nothing)
+            ad_u = bytedot4(xl, 0x03020100u, ad_u);
+            ad_u = bytedot4(xh, 0x07060504u, ad_u);
+            ad_s1 += s;
+            ad_s2 += ad_k * s;
+            ad_k++;
         }
         const bool nz = valid && x != 0;
         const uint32_t tzb = nz ? (uint32_t)__builtin_ctzll(x) >> 3 : 0;
@@ -466,11 +484,12 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
             carry += 8u * nvalid;
         }
         if (enc.qbits - enc.qflushed > kEncRingBits / 2) enc.flush(false);
-        if (((t0 >> 6) & 0xFFF) == 0xFFF) {  // keep the 64-bit Adler partials far from overflow
-            acc_a %= kAdlerMod;
-            acc_b %= kAdlerMod;
+        if (ad_k == 256) {  // (256 tiles x 255 x 2 040 < 2^32: the 32-bit sums cannot overflow)
+            adler_fold();
+            ad_f0 = t0 + kWave;
         }
     }
+    adler_fold();
     // ---- pending run at the end of the chunked part (ultrafast.rs:155-157) ----
     if (carry > 0) enc.emit_run_uniform(carry);
     // ---- remainder bytes as literals (ultrafast.rs:159-164) ----
