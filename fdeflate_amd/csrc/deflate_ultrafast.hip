@@ -411,15 +411,13 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
         }
         const uint32_t drop_lo = 2 * lo, drop = drop_lo + 2 * lzb;
         uint32_t lit_n = 0;       // bits of the chunk's literals
-        uint64_t l0 = 0, l1 = 0;  // ... and the bits themselves (<= 96)
+        uint64_t f0 = 0, f1 = 0;  // the codes of all eight bytes (<= 96 bits); the low drop_lo of them belong to dropped zero bytes
         {
             const uint64_t la = (uint64_t)pb[0] | ((uint64_t)pb[1] << pn[0]);
             const uint64_t lb = (uint64_t)pb[2] | ((uint64_t)pb[3] << pn[2]);
             const uint32_t na = pn[0] + pn[1];  // <= 48, >= 4
-            const uint64_t f0 = la | (lb << na);
-            const uint64_t f1 = lb >> (64 - na);
-            l0 = drop_lo ? (f0 >> drop_lo) | (f1 << (64 - drop_lo)) : f0;
-            l1 = f1 >> drop_lo;
+            f0 = la | (lb << na);
+            f1 = lb >> (64 - na);
             lit_n = nz ? na + pn[2] + pn[3] - drop : 0u;
         }
         // ---- run closed by this chunk (write_run, ultrafast.rs:45-67) ----
@@ -446,6 +444,7 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
                 uint32_t P_l = __shfl(P, l, kWave), tz_l = __shfl(tzb, l, kWave);
                 if (p_l) enc.emit_run_uniform(P_l + tz_l);
                 uint32_t left = __shfl(lit_n, l, kWave);
+                const uint64_t l0 = drop_lo ? (f0 >> drop_lo) | (f1 << (64 - drop_lo)) : f0, l1 = f1 >> drop_lo;
                 const uint32_t w[3] = {(uint32_t)__shfl((int)(uint32_t)l0, l, kWave), (uint32_t)__shfl((int)(uint32_t)(l0 >> 32), l, kWave),
                                        (uint32_t)__shfl((int)(uint32_t)l1, l, kWave)};
 #pragma unroll
@@ -457,8 +456,7 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
             }
         } else {
             uint64_t pos = enc.qbits + off;
-            // the run's leading literal 0 (two zero bits) and its full-length repeats (rare) ...
-            uint32_t pre_bits = 0, pre_n = 0;
+            // the run's leading literal 0 (two zero bits), its full-length repeats (rare) and its tail ...
             if (pend) {
                 pos += 2;
                 uint32_t rep_bits = e285 & 0xFFFF;
@@ -467,13 +465,14 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
                     enc.or_bits(pos, rep_bits);
                     pos += rep_n;
                 }
-                pre_bits = tail_bits;  // ... then the tail of the run in front of the chunk's literals
-                pre_n = tail_n;
+                enc.or_bits(pos, tail_bits);
+                pos += tail_n;
             }
-            // ... and the chunk's literals: <= 22 + 96 bits
-            const uint64_t v0 = (uint64_t)pre_bits | (l0 << pre_n);
-            const uint64_t v1 = (l1 << pre_n) | (pre_n ? l0 >> (64 - pre_n) : 0);
-            enc.or_bits128(pos, v0, v1);
+            // ... and the chunk's literals.  (round 6) The string of all eight codes goes in as it is, drop_lo bits EARLY:
+            // its low drop_lo bits are the codes of the zero bytes the run has swallowed -- zeros, which change nothing
+            // where they fall -- so the 96-bit string is shifted once (into its place in the ring), not three times
+            // (out of the dropped bits, behind the run's tail, into place).
+            enc.or_bits128(pos - drop_lo, f0, f1);
             enc.qbits += total;
         }
         // ---- carry: pending run after this tile ----
