@@ -84,6 +84,7 @@ __device__ __forceinline__ uint32_t g_hash(uint64_t v) { return (uint32_t)((1140
 
 #ifdef FDH_DEBUG_GEN
 __device__ uint64_t g_gen_t[8][32768];
+__device__ uint32_t g_gen_w[12][32768];  // block writer: walk 1, prepare, merges (+ depths), limit / codes, header, walk 2, -, whole
 #define GT0(k) const uint64_t _t##k = __builtin_readcyclecounter()
 #define GT1(k) tacc[k] += __builtin_readcyclecounter() - _t##k
 #else
@@ -699,14 +700,20 @@ __device__ uint64_t g_heap_pop(uint64_t* d, uint32_t& len) {
 
 // Whole wavefront: clear the lengths, put the used symbols on the heap array in index order
 // (bitstream.rs:200-222: `for (i, &f) in frequencies.iter().enumerate()` pushes in that order).
-__device__ void g_huff_prepare(const GHuffView& v, int lane) {
+template <bool PACKED>
+__device__ __forceinline__ void g_huff_prepare(const GHuffView& v, int lane) {
+    uint32_t* const d32 = reinterpret_cast<uint32_t*>(v.heap);
     uint32_t hl = 0;
     for (uint32_t base = 0; base < v.n; base += kWave) {
         const uint32_t i = base + lane;
         const uint32_t f = i < v.n ? v.freq[i] : 0;
         if (i < v.n) v.lengths[i] = 0;
         const uint64_t m = __ballot(f > 0);
-        if (f > 0) v.heap[hl + __popcll(m & lanemask_lt(lane))] = ((uint64_t)f << 32) | i;
+        if (f > 0) {
+            const uint32_t at = hl + (uint32_t)__popcll(m & lanemask_lt(lane));
+            if (PACKED) d32[at] = (f << 10) | i;
+            else v.heap[at] = ((uint64_t)f << 32) | i;
+        }
         hl += (uint32_t)__popcll(m);
     }
     if (lane == 0) {
@@ -715,6 +722,8 @@ __device__ void g_huff_prepare(const GHuffView& v, int lane) {
         v.hdr[2] = 0;
     }
 }
+
+__device__ void g_huff_depths(const GHuffView& v, uint32_t ni);
 
 // One lane: the order-dependent part -- heapify, merge, depths, length limiting.
 __device__ void g_huff_serial(const GHuffView& v) {
@@ -741,8 +750,13 @@ __device__ void g_huff_serial(const GHuffView& v) {
         v.heap[0] = ((uint64_t)(hf(a) + hf(b)) << 32) | (ni + N - 1);
         g_sift_down_range(v.heap, 0, hl);  // PeekMut::drop
     }
-    // :247-259 depth of every leaf; a node is always created after its children, so one pass from
-    // the root (the last internal node) down the creation order visits parents first
+    g_huff_depths(v, ni);
+}
+
+// One lane: :247-259 depth of every leaf; a node is always created after its children, so one pass from
+// the root (the last internal node) down the creation order visits parents first
+__device__ void g_huff_depths(const GHuffView& v, uint32_t ni) {
+    const uint32_t N = v.n;
     uint32_t max_length = 0;
     v.depth[ni - 1] = 0;
     for (uint32_t k = ni; k > 0;) {
@@ -763,6 +777,145 @@ __device__ void g_huff_serial(const GHuffView& v) {
         }
     }
     v.hdr[2] = max_length;
+}
+
+// ---- The same heap with one dword per item: frequency << 10 | node index. ----
+// With 64-bit items on one lane the sifts were 42 % of the block writer's time (measured by running them
+// twice).  Node indices stay below 572 and the caller checks that the block's symbol count stays below 2^22
+// (else the 64-bit version above runs), so an item fits a dword, both children come with one ds_read2_b32,
+// and "a.f >= b.f" is (a | 0x3FF) >= b: the index bits of b never exceed the ten ones or-ed into a.
+__device__ __forceinline__ bool p_ge(uint32_t x, uint32_t y) { return (x | 0x3FFu) >= y; }
+
+template <typename P>  // (uint32_t* or its LDS-qualified form)
+__device__ __forceinline__ void p_sift_down_range(P d, uint32_t pos, uint32_t end) {
+    const uint32_t elem = d[pos];
+    uint32_t hole = pos, child = 2 * hole + 1;
+    while (child + 1 < end) {  // two children
+        const uint32_t c0 = d[child], c1 = d[child + 1];
+        const bool right = p_ge(c0, c1);  // d[child] <= d[child + 1]
+        const uint32_t c = right ? c1 : c0;
+        if (p_ge(c, elem)) {  // elem >= d[child]
+            d[hole] = elem;
+            return;
+        }
+        d[hole] = c;
+        hole = right ? child + 1 : child;
+        child = 2 * hole + 1;
+    }
+    if (child + 1 == end) {
+        const uint32_t c = d[child];
+        if (!p_ge(c, elem)) {  // elem < d[child]
+            d[hole] = c;
+            hole = child;
+        }
+    }
+    d[hole] = elem;
+}
+
+// ---- The merges on the whole wavefront: a sift is a path, and a path is found without touching the items. ----
+// sift_down_to_bottom follows the smaller child at every level, and sift_down_range follows the same path until the
+// moving item fits; which child is the smaller one is a property of the heap, not of the moving item.  So: every lane
+// compares the two children of "its" nodes (positions lane, 64 + lane, 128 + lane) and three ballots hold the
+// decision of every node; the path from the root is then scalar bit arithmetic (position p -> 2p + bit(p), positions
+// 1-based so that the ancestors of the bottom position P are P >> 1, P >> 2, ...); lane k fetches the item at the
+// path's level k, one ballot finds where the moving item stops (pop: the sift_up of the last item from the bottom;
+// PeekMut::drop: the first level whose item is not smaller), and the lanes above that level each store their
+// neighbour's item one level up.  Two LDS round trips and ~60 instructions per sift instead of ~28 instructions and a
+// round trip per LEVEL of it on one lane.  Items behind the heap's end are kept at 0xFFFFFFFF (a frequency no packed
+// item reaches), so a node with one child goes left and the path ends where the heap ends.  The comparisons are the
+// ones of p_sift_down_range / p_heap_pop, in an order that cannot be observed: same heap after every step.
+// LEVELS = 8: the literal/length tree (at most 288 items, 576 dwords of array); 5: the small trees (at most 32 items,
+// 64 dwords).  v.hdr[0] = items, in index order as g_huff_prepare<true> left them.  The loop is written for its
+// instruction count: no branch in a sift, the path is computed to full depth and cut where it leaves the heap.
+template <int LEVELS>
+__device__ __noinline__ void g_huff_merges_wave(const GHuffView v, const int lane) {
+    constexpr uint32_t kCap = LEVELS == 8 ? 576 : 64;
+    const uint32_t N = v.n;
+    // (the view's pointers are generic: behind a call the compiler no longer sees that they are LDS addresses)
+    using lds_u32 = __attribute__((address_space(3))) uint32_t;
+    using lds_u16 = __attribute__((address_space(3))) uint16_t;
+    lds_u32* const d = (lds_u32*)reinterpret_cast<uint32_t*>(v.heap);
+    lds_u16* const in_left = (lds_u16*)v.in_left;
+    lds_u16* const in_right = (lds_u16*)v.in_right;
+    uint32_t hl = uni(v.hdr[0]);
+    if (hl <= 1) {  // :206-213 nothing or a single symbol (length 1)
+        if (hl == 1 && lane == 0) {
+            v.lengths[d[0] & 0x3FFu] = 1;
+            v.hdr[2] = 1;
+        }
+        return;
+    }
+    for (uint32_t i = hl + (uint32_t)lane; i < kCap; i += kWave) d[i] = 0xFFFFFFFFu;
+    wave_sync();
+    // BinaryHeap::from(vec): sift_down_range(k, len) for k = len / 2 - 1 .. 0.  The nodes of one level have disjoint
+    // subtrees, so a level's sifts run side by side, one lane each; levels bottom-up as in the sequential order.
+    for (int lev = 31 - __clz((int)(hl / 2)); lev >= 0; lev--) {
+        const uint32_t first = 1u << lev, last_node = min(2 * first - 1, hl / 2);
+        for (uint32_t node = first + (uint32_t)lane; node <= last_node; node += kWave) p_sift_down_range(d, node - 1, hl);
+        wave_sync();
+    }
+    const lds_u32* const d1 = d - 1;  // position p (1-based) is d1[p]
+    // the children of "this lane's" nodes: positions 2q, 2q + 1 for q = lane, 64 + lane, 128 + lane
+    const uint32_t q0 = LEVELS == 8 ? (lane ? (uint32_t)lane : 1u) : (lane ? (uint32_t)lane & 31u : 1u);
+    const lds_u32* const c0 = d1 + 2 * q0;
+    const lds_u32* const c1 = d1 + 2 * (64 + (uint32_t)lane);
+    const lds_u32* const c2 = d1 + 2 * (128 + (uint32_t)lane);
+    const uint32_t lv = (uint32_t)(LEVELS - lane) & 31u;  // lane k looks at level k of a path
+    const uint64_t lanes_on_path = ((uint64_t)2 << LEVELS) - 1;
+    // The path from the root along the smaller children, as its position at level LEVELS (it leaves the heap on the
+    // way when the heap is shallower); `pk` = this lane's position on it, `vmask` = the lanes whose level exists.
+    auto path = [&](uint32_t end, uint32_t& pk, uint64_t& vmask) __attribute__((always_inline)) {
+        const uint64_t m0 = __ballot(p_ge(c0[0], c0[1]));
+        uint32_t p = 1;
+        // p = 2p + bit p of the mask (s_bitcmp1_b64 looks at the low six bits of p; the carry doubles and adds)
+#define FDH_PATH_STEP(m) asm("s_bitcmp1_b64 %1, %0\n\ts_addc_u32 %0, %0, %0" : "+s"(p) : "s"(m) : "scc")
+#pragma unroll
+        for (int l = 0; l < (LEVELS < 6 ? LEVELS : 6); l++) FDH_PATH_STEP(m0);
+        if (LEVELS == 8) {
+            const uint64_t m1 = __ballot(p_ge(c1[0], c1[1]));
+            const uint64_t m2 = __ballot(p_ge(c2[0], c2[1]));
+            FDH_PATH_STEP(m1);
+            FDH_PATH_STEP(m2);
+        }
+#undef FDH_PATH_STEP
+        const uint32_t mine = p >> lv;
+        vmask = __ballot(mine <= end) & lanes_on_path;
+        pk = mine <= end ? mine : 1u;
+    };
+    uint32_t ni = 0;
+    while (hl > 1) {  // :236-244
+        // ---- pop: the last item goes to the root, sift_down_to_bottom(0), then sift_up ----
+        const uint32_t end = hl - 1;
+        const uint32_t last_v = d[end];
+        if (lane == 0) d[end] = 0xFFFFFFFFu;
+        uint32_t pk;
+        uint64_t vmask;
+        path(end, pk, vmask);
+        uint32_t x = d1[pk];
+        const uint32_t last = uni(last_v);
+        // elem <= d[parent] at level k - 1, whose item came up from level k: the sift_up stops there
+        const uint64_t stay = __ballot(p_ge(last, x)) & vmask & ~(uint64_t)1;
+        const uint32_t j = stay ? 63 - (uint32_t)__clzll((long long)stay) : 0u;
+        uint32_t xn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, false);  // row_shl:1: lane k + 1's item
+        if ((uint32_t)lane <= j) d[pk - 1] = (uint32_t)lane == j ? last : xn;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0);
+        const uint32_t b = j == 0 ? last : (uint32_t)__builtin_amdgcn_readlane((int)x, 1);
+        // ---- the root takes the merged node; PeekMut::drop sifts it down ----
+        if (lane == 0) {
+            in_left[ni] = (uint16_t)(a & 0x3FFu);
+            in_right[ni] = (uint16_t)(b & 0x3FFu);
+        }
+        ni++;
+        const uint32_t elem = (((a >> 10) + (b >> 10)) << 10) | (ni + N - 1);
+        path(end, pk, vmask);
+        x = d1[pk];
+        const uint64_t stop = __ballot(p_ge(x, elem)) & vmask & ~(uint64_t)1;  // elem >= d[child]
+        const uint32_t sl = stop ? (uint32_t)__ffsll((long long)stop) - 1 : (uint32_t)__popcll(vmask);  // elem goes to level sl - 1
+        xn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, false);
+        if ((uint32_t)lane < sl) d[pk - 1] = (uint32_t)lane == sl - 1 ? elem : xn;
+        hl = end;
+    }
+    wave_sync();
 }
 
 // Whole wavefront: length limiting (:262-305) when the tree came out deeper than `limit`.
@@ -1040,6 +1193,19 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
 
     uint64_t acc_a = 0, acc_b = 0;
     uint32_t b0 = 0, m0 = 0;
+#ifdef FDH_DEBUG_GEN
+    uint32_t wt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t wt_all = __builtin_readcyclecounter();
+    uint64_t wt_last = wt_all;
+#define GW_T(k)                                              \
+    {                                                        \
+        const uint64_t now_ = __builtin_readcyclecounter();  \
+        wt[k] += (uint32_t)(now_ - wt_last);                 \
+        wt_last = now_;                                      \
+    }
+#else
+#define GW_T(k)
+#endif
     for (uint32_t blk = 0; blk < nblocks; blk++) {
         const uint32_t b1 = uni(blks[blk].end_pos), m1 = uni(blks[blk].match_end), flags = uni(blks[blk].flags);
         if (flags & kGBlockEmptyFixed) {  // compress/mod.rs:234-238: BFINAL, fixed codes, end of block; flush
@@ -1051,19 +1217,40 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
         if (lane < 32) lds.dfreq[lane] = 0;
         if (lane < 20) lds.clfreq[lane] = 0;
         wave_sync();
+        GW_T(6)
         g_walk<false>(lds, br, in, recs, b0, b1, m0, m1, len, acc_a, acc_b);
+        GW_T(0)
         // ---- the two code tables (:68-73) ----
         const GHuffView vl = g_view(lds.h.big, lds.freq, 286, 15), vd = g_view(lds.h.small, lds.dfreq, 30, 15);
-        g_huff_prepare(vl, lane);
-        g_huff_prepare(vd, lane);
+        // (packed heap items hold 22 bits of frequency: a block's symbols number at most its positions + 1)
+        const bool packed = b1 - b0 < (1u << 22) - 2;
+        if (packed) {
+            g_huff_prepare<true>(vl, lane);
+            g_huff_prepare<true>(vd, lane);
+            wave_sync();
+            GW_T(1)
+            g_huff_merges_wave<8>(vl, lane);
+            GW_T(8)
+            g_huff_merges_wave<5>(vd, lane);
+            GW_T(9)
+            if (lane < 2) {
+                const GHuffView vv = lane == 0 ? vl : vd;
+                if (vv.hdr[0] > 1) g_huff_depths(vv, vv.hdr[0] - 1);
+            }
+        } else {
+            g_huff_prepare<false>(vl, lane);
+            g_huff_prepare<false>(vd, lane);
+            wave_sync();
+            if (lane < 2) g_huff_serial(lane == 0 ? vl : vd);
+        }
         wave_sync();
-        if (lane < 2) g_huff_serial(lane == 0 ? vl : vd);
-        wave_sync();
+        GW_T(2)
         if (uni(lds.h.big.max_length) > 15) g_huff_limit(vl, lds.h.big.first, lane);
         if (uni(lds.h.small.max_length) > 15) g_huff_limit(vd, lds.h.small.first, lane);
         g_huff_codes(vl, lds.cl, lds.h.big.first, lane);
         g_huff_codes(vd, lds.dcl, lds.h.small.first, lane);
         wave_sync();
+        GW_T(3)
         // ---- header (:75-119): counts trimmed of trailing zero lengths, the code-length code ----
         uint32_t num_litlen = 286, num_dist = 30;
         if (lane == 0) {
@@ -1082,9 +1269,12 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
             // the code-length tree reuses the small scratch: move the distance lengths out first
             // (they live on in dcl[] >> 16)
             const GHuffView vc = g_view(lds.h.small, lds.clfreq, 19, 7);
-            g_huff_prepare(vc, lane);
+            g_huff_prepare<true>(vc, lane);  // (at most 316 code lengths: always packed)
             wave_sync();
-            if (lane == 0) g_huff_serial(vc);
+            GW_T(4)
+            g_huff_merges_wave<5>(vc, lane);
+            GW_T(10)
+            if (lane == 0 && vc.hdr[0] > 1) g_huff_depths(vc, vc.hdr[0] - 1);
             wave_sync();
             if (uni(lds.h.small.max_length) > 7) g_huff_limit(vc, lds.h.small.first, lane);
             g_huff_codes(vc, lds.clcl, lds.h.small.first, lane);
@@ -1110,9 +1300,11 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
             br.qbits += total;
         }
         wave_sync();
+        GW_T(4)
         // ---- the symbols, end of block (:121-194) ----
         g_walk<true>(lds, br, in, recs, b0, b1, m0, m1, len, acc_a, acc_b);
         br.emit_uniform(lds.cl[256] & 0xFFFF, lds.cl[256] >> 16);
+        GW_T(5)
         b0 = b1;
         m0 = m1;
     }
@@ -1124,11 +1316,19 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
     br.emit_uniform(__builtin_bswap32((B << 16) | A), 32);
     br.flush(true);
     if (lane == 0) a.out_len[sid] = br.overflow ? 0xFFFFFFFFu : (uint32_t)((br.qbits >> 3) - br.gmis);
+#ifdef FDH_DEBUG_GEN
+    wt[7] = (uint32_t)(__builtin_readcyclecounter() - wt_all);
+    if (lane == 0 && sid < 32768)
+        for (int k = 0; k < 12; k++) g_gen_w[k][sid] = wt[k];
+#endif
 }
 
 }  // namespace fdh
 
 #ifdef FDH_DEBUG_GEN
+extern "C" int fdh_debug_gen_write_timers(uint32_t* host /* 8 x 32768 */) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_gen_w), sizeof(uint32_t) * 12 * 32768);
+}
 extern "C" int fdh_debug_gen_timers(uint64_t* host /* 8 x 32768 */) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fdh::g_gen_t), sizeof(uint64_t) * 8 * 32768);
 }

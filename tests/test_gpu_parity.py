@@ -672,6 +672,12 @@ def test_ultrafast_encode_bit_exact(harness):
     for i in (0, 1, 7, 15, 16, 23):
         raws.append(synth.gen_stream_np(i, 65536).tobytes())
     raws.append(bytes(3_000_000) + b"\x07" + bytes(100))  # a run too long for the LDS bit ring
+    # around and beyond 256 tiles (128 KiB), where the 32-bit Adler partial sums are folded; 0xFF is their worst case
+    for n in (131071, 131072, 131073, 131072 * 3 + 5, (1 << 20) + 3):
+        raws.append(bytes([255]) * n)
+        x = r.integers(0, 256, n, dtype=np.uint8)
+        x[r.random(n) < 0.3] = 0
+        raws.append(x.tobytes())
     res, ok = harness.gpu_deflate(raws)
     assert ok
     for i, raw in enumerate(raws):
@@ -1015,6 +1021,30 @@ def test_general_encoder_level1_and_rle_bit_exact(harness):
             os.environ.pop("FDH_GEN_LANES", None)
         else:
             os.environ["FDH_GEN_LANES"] = old
+
+
+def test_general_encoder_block_longer_than_the_packed_heap_items(harness):
+    """A block's Huffman merges run on one-dword heap items (22 bits of frequency) and fall back to the 64-bit items
+    when the block covers 2^22 positions or more: 4.5 MiB of bytes without repeats is ONE block (a literal run counts
+    as one symbol towards the 16 384 of a block) in both modes; bit-exact with the oracle, next to a short stream."""
+    import torch
+    import fdeflate_amd as fd
+    r = np.random.default_rng(23)
+    raws = [r.integers(0, 256, 4_718_592 + 11, dtype=np.uint8).tobytes(), b"abcabcabcabc" * 50]
+    buf, in_off = streams.pack_exact(raws)
+    caps = [fd.compress_bound(len(x)) + 5 for x in raws]
+    out_off = np.zeros(len(raws) + 1, dtype=np.int64)
+    out_off[1:] = np.cumsum(caps)
+    d_in = torch.from_numpy(buf).cuda()
+    d_in_off = torch.from_numpy(in_off.astype(np.int64)).cuda()
+    d_out_off = torch.from_numpy(out_off).cuda()
+    for mode, enc in ((fd.MODE_LEVEL1, ob.compress_level1), (fd.MODE_RLE, ob.compress_rle)):
+        d_out = torch.full((int(out_off[-1]),), 0x5A, dtype=torch.uint8, device="cuda")
+        ln = fd.deflate_general_batch(d_in, d_in_off, d_out, d_out_off, mode).cpu().numpy().view(np.uint32)
+        h = d_out.cpu().numpy()
+        for i, raw in enumerate(raws):
+            exp = enc(raw)
+            assert h[out_off[i]:out_off[i] + int(ln[i])].tobytes() == exp, (mode, i, int(ln[i]), len(exp))
 
 
 def test_general_encoder_roundtrip_at_scale(harness):

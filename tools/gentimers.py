@@ -33,5 +33,13 @@ for mode, label in ((fd.MODE_LEVEL1, "level 1"), (fd.MODE_RLE, "rle")):
     for k, nm in enumerate(names):
         if nm:
             print("%-28s %12.0f %12.0f" % (nm, t[k].mean(), t[k].max()))
+    w = np.zeros((12, 32768), dtype=np.uint32)
+    assert lib.fdh_debug_gen_write_timers(w.ctypes.data_as(C.c_void_p)) == 0
+    w = w[:, :min(n, 32768)].astype(np.float64)
+    print("== %s, block writer: clocks per stream (mean), share" % label)
+    for k, nm in enumerate(["walk 1 (frequencies)", "prepare", "depths (one lane)", "limit / codes", "header", "walk 2 (symbols)", "block set-up", "whole stream", "  merges, literal/length tree", "  merges, distance tree", "  merges, code-length tree", ""]):
+        if not nm:
+            continue
+        print("%-28s %12.0f %6.1f %%" % (nm, w[k].mean(), 100 * w[k].mean() / w[7].mean()))
     heavy = np.argsort(t[7])[-3:]
     print("heaviest streams:", heavy.tolist(), (t[:, heavy] / 1e3).astype(int).T.tolist())
