@@ -1026,22 +1026,11 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
     return x;
 }
 
-// Appends `n` bits (n <= 48) to the value {v1:v0} that holds `nb` bits (nb + n <= 128).
-__device__ __forceinline__ void g_append(uint64_t& v0, uint64_t& v1, uint32_t& nb, uint64_t bits, uint32_t n) {
-    if (nb < 64) {
-        v0 |= bits << nb;
-        if (nb + n > 64) v1 |= bits >> (64 - nb);
-    } else {
-        v1 |= bits << (nb - 64);
-    }
-    nb += n;
-}
-
 // One walk over the positions [b0, b1) of a block whose back-references are recs[m0, m1).
 // EMIT = false: symbol frequencies (bitstream.rs:42-66); EMIT = true: the symbols (:121-186).
 // Every lane takes four consecutive positions per step (256 per wavefront): back-references are at
-// least four bytes long, so a lane sees at most one or two of them and its codes stay below the
-// 118 bits one ring update takes.
+// least three bytes long, so a lane sees at most two of them and its codes stay below the 118 bits
+// one ring update takes.
 // The loads of the walk (the next step's four bytes, the next chunk's records) are UNCONDITIONAL,
 // from clamped addresses: behind a load in a branch the compiler has to wait for every load in
 // flight at the join, the prefetch it has just issued included.  (`in` has at least four readable
@@ -1089,54 +1078,99 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
             if (nact < 4) word &= nact ? (1u << (8 * nact)) - 1 : 0u;  // (the bytes behind belong to the next block)
             uint4 mk4 = *reinterpret_cast<const uint4*>(&lds.marks[p0 - c0]);
             if (mk4.x | mk4.y | mk4.z | mk4.w) *reinterpret_cast<uint4*>(&lds.marks[p0 - c0]) = make_uint4(0, 0, 0, 0);
-            const uint32_t mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
-            uint32_t e = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (mk[j]) e = p0 + j + (mk[j] & 0x1FF);
+            // At most two back-references start in a lane's four positions (they are at least three bytes long): the
+            // first of them, A, and B at the fourth position behind a three-byte A at the first.  They are looked at
+            // once each instead of once per position, and the positions between are told apart without a branch.
+            const uint32_t mk0 = mk4.x, mk1 = mk4.y, mk2 = mk4.z, mk3 = mk4.w;
+            const uint32_t mA = mk0 ? mk0 : (mk1 ? mk1 : (mk2 ? mk2 : mk3));
+            const uint32_t jA = mk0 ? 0u : (mk1 ? 1u : (mk2 ? 2u : 3u));
+            const bool hasA = mA != 0, hasB = mk0 != 0 && mk3 != 0;
+            const uint32_t lenA = mA & 0x1FF, endA = p0 + jA + lenA;
+            const uint32_t lenB = mk3 & 0x1FF, endB = p0 + 3 + lenB;
+            const uint32_t e = hasB ? endB : (hasA ? endA : 0u);
             const uint32_t incl = wave_incl_max_u32(e);
-            const uint32_t before = (uint32_t)__shfl_up((int)incl, 1, kWave);
-            uint32_t cov = max(covered, lane ? before : 0u);  // end of the last back-reference in front of p0
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xF, 0xF, false);  // wave_shr:1
+            const uint32_t cov = max(covered, before);  // end of the last back-reference in front of p0
             covered = max(covered, (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1));
             if (EMIT) {  // Adler-32 partial sums: A = 1 + sum d_i, B = len + sum (len - i) d_i
                 const uint32_t sum = bytesum4(word);
                 acc_a += sum;
                 acc_b += (len - p0) * sum - bytedot4(word, 0x03020100u, 0);
             }
-            uint64_t v0 = 0, v1 = 0;
-            uint32_t nb = 0;
+            // a literal: no back-reference starts there, and it lies behind the last one's end (A's, behind A)
+            bool lit[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t p = p0 + j, byte = (word >> (8 * j)) & 0xFF;
-                if (mk[j]) {
-                    const uint32_t length = mk[j] & 0x1FF, ds = (mk[j] >> 9) & 31;
-                    uint32_t sym, extra;
-                    g_length_symbol(length, sym, extra);
-                    cov = p + length;
-                    if (!EMIT) {
+                const uint32_t mkj = j == 0 ? mk0 : (j == 1 ? mk1 : (j == 2 ? mk2 : mk3));
+                lit[j] = mkj == 0 && (uint32_t)j < nact && p0 + j >= ((hasA && (uint32_t)j > jA) ? endA : cov);
+            }
+            uint64_t v0 = 0, v1 = 0;
+            uint32_t nb = 0;
+            if (!EMIT) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (lit[j]) atomicAdd(&lds.freq[(word >> (8 * j)) & 0xFF], 1u);
+                if (__any(hasA)) {
+                    if (hasA) {
+                        uint32_t sym, extra;
+                        g_length_symbol(lenA, sym, extra);
                         atomicAdd(&lds.freq[sym], 1u);
-                        atomicAdd(&lds.dfreq[ds], 1u);
-                    } else {  // :163-185 length code, length extra bits, distance code, distance extra bits
-                        const uint32_t el = lds.cl[sym], d = lds.dcl[ds], dm = lds.dmeta[ds];
-                        const uint32_t distance = ((mk[j] >> 14) & 0x7FFF) + 1;
-                        uint64_t v = el & 0xFFFF;
-                        uint32_t n = el >> 16;
-                        v |= (uint64_t)((length - 3) & ((1u << extra) - 1)) << n;
-                        n += extra;
-                        v |= (uint64_t)(d & 0xFFFF) << n;
-                        n += d >> 16;
-                        v |= (uint64_t)(distance - (dm & 0xFFFF)) << n;
-                        n += dm >> 16;
-                        g_append(v0, v1, nb, v, n);
+                        atomicAdd(&lds.dfreq[(mA >> 9) & 31], 1u);
                     }
-                } else if ((uint32_t)j < nact && p >= cov) {  // a literal
-                    if (!EMIT) {
-                        atomicAdd(&lds.freq[byte], 1u);
-                    } else {
-                        const uint32_t el = lds.cl[byte];
-                        g_append(v0, v1, nb, el & 0xFFFF, el >> 16);
+                    if (__any(hasB)) {
+                        if (hasB) {
+                            uint32_t sym, extra;
+                            g_length_symbol(lenB, sym, extra);
+                            atomicAdd(&lds.freq[sym], 1u);
+                            atomicAdd(&lds.dfreq[(mk3 >> 9) & 31], 1u);
+                        }
                     }
                 }
+            } else {
+                // :163-185 length code, length extra bits, distance code, distance extra bits: at most 48 bits
+                auto piece = [&](uint32_t m, uint32_t length, uint64_t& v, uint32_t& n) __attribute__((always_inline)) {
+                    uint32_t sym, extra;
+                    g_length_symbol(length, sym, extra);
+                    const uint32_t ds = (m >> 9) & 31;
+                    const uint32_t el = lds.cl[sym], d = lds.dcl[ds], dm = lds.dmeta[ds];
+                    const uint32_t distance = ((m >> 14) & 0x7FFF) + 1;
+                    uint32_t lo = el & 0xFFFF;
+                    n = el >> 16;
+                    lo |= ((length - 3) & ((1u << extra) - 1)) << n;  // (15 + 5 bits)
+                    n += extra;
+                    v = lo | ((uint64_t)(d & 0xFFFF) << n);
+                    n += d >> 16;
+                    v |= (uint64_t)(distance - (dm & 0xFFFF)) << n;
+                    n += dm >> 16;
+                };
+                uint32_t el[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    el[j] = lds.cl[(word >> (8 * j)) & 0xFF];
+                    el[j] = lit[j] ? el[j] : 0u;
+                }
+                uint64_t vA = 0, vB = 0;
+                uint32_t nA = 0, nB = 0;
+                if (__any(hasA)) {
+                    if (hasA) piece(mA, lenA, vA, nA);
+                    if (__any(hasB))
+                        if (hasB) piece(mk3, lenB, vB, nB);
+                }
+                // The literals in front of A (behind it the lane's positions are covered, but for the fourth behind a
+                // three-byte A at the first), A, then the fourth position's literal or B.  Every piece lands below bit
+                // 64 (at most 45 bits of literals in front of A; A alone, at most 48, in front of the fourth), so only A
+                // and the fourth can spill into the high half.
+                const uint32_t n0 = el[0] >> 16, n1 = el[1] >> 16, n2 = el[2] >> 16;
+                const uint32_t nfront = n0 + n1 + n2;
+                v0 = ((el[0] & 0xFFFF) | ((el[1] & 0xFFFF) << n0)) | ((uint64_t)(el[2] & 0xFFFF) << (n0 + n1));
+                v0 |= vA << nfront;
+                v1 = (vA >> 1) >> (63 - nfront);
+                const uint64_t vT = hasB ? vB : (uint64_t)(el[3] & 0xFFFF);
+                const uint32_t nT = hasB ? nB : el[3] >> 16;
+                const uint32_t at = nfront + nA;  // (64 or more only where the fourth position is covered: vT = 0)
+                v0 |= vT << (at & 63);
+                v1 |= (vT >> 1) >> ((63 - at) & 63);
+                nb = at + nT;
             }
             if (EMIT) {
                 uint32_t total;
