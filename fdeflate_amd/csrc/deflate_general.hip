@@ -1026,6 +1026,16 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
     return x;
 }
 
+// table[idx] += 1 in the lanes that are `on` (some lane is): the lanes that agree with the first of them in one add.
+__device__ __forceinline__ void g_count(uint32_t* table, uint32_t idx, bool on, int lane) {
+    const uint64_t act = __ballot(on);
+    const int first = __ffsll((unsigned long long)act) - 1;
+    const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)idx, first);
+    const uint64_t same = __ballot(on && idx == v0);
+    if (lane == first) atomicAdd(&table[v0], (uint32_t)__popcll(same));
+    if (on && idx != v0) atomicAdd(&table[idx], 1u);
+}
+
 // One walk over the positions [b0, b1) of a block whose back-references are recs[m0, m1).
 // EMIT = false: symbol frequencies (bitstream.rs:42-66); EMIT = true: the symbols (:121-186).
 // Every lane takes four consecutive positions per step (256 per wavefront): back-references are at
@@ -1054,6 +1064,7 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
     };
     const uint32_t mlast = m1 ? m1 - 1 : 0;  // (the slice has at least two records, used or not)
     uint32_t mc = m0, covered = b0;  // next record to mark; end of the last back-reference so far
+    uint32_t zeros = 0;              // literal zeros of the frequency walk (wavefront-uniform)
     uint32_t word_next = load4(b0 + 4 * lane);
     GMatchRec rnext = recs[min(mc + lane, mlast)];
     for (uint32_t c0 = b0; c0 < b1; c0 += kGChunk) {
@@ -1108,18 +1119,22 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
             uint32_t nb = 0;
             if (!EMIT) {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (lit[j]) atomicAdd(&lds.freq[(word >> (8 * j)) & 0xFF], 1u);
+                // An LDS atomic takes one pass per lane that shares its address, and filtered image bytes share a lot:
+                // a quarter of the literals are zeros (the zeros too isolated for a run), every run's distance code is
+                // the same.  The zeros are counted by ballot and added once per walk; of the back-references the lanes
+                // that agree with the first one are counted once.
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t byte = (word >> (8 * j)) & 0xFF;
+                    zeros += (uint32_t)__popcll(__ballot(lit[j] && byte == 0));
+                    if (lit[j] && byte != 0) atomicAdd(&lds.freq[byte], 1u);
+                }
                 if (__any(hasA)) {
-                    if (hasA) {
-                        uint32_t sym, extra;
-                        g_length_symbol(lenA, sym, extra);
-                        atomicAdd(&lds.freq[sym], 1u);
-                        atomicAdd(&lds.dfreq[(mA >> 9) & 31], 1u);
-                    }
+                    uint32_t sym = 0, extra;
+                    if (hasA) g_length_symbol(lenA, sym, extra);
+                    g_count(lds.freq, sym, hasA, (int)lane);
+                    g_count(lds.dfreq, (mA >> 9) & 31, hasA, (int)lane);
                     if (__any(hasB)) {
                         if (hasB) {
-                            uint32_t sym, extra;
                             g_length_symbol(lenB, sym, extra);
                             atomicAdd(&lds.freq[sym], 1u);
                             atomicAdd(&lds.dfreq[(mk3 >> 9) & 31], 1u);
@@ -1182,6 +1197,7 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
             }
         }
     }
+    if (!EMIT && lane == 0 && zeros) atomicAdd(&lds.freq[0], zeros);
     wave_sync();
 }
 
