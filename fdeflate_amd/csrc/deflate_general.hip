@@ -812,6 +812,76 @@ __device__ __forceinline__ void p_sift_down_range(P d, uint32_t pos, uint32_t en
     d[hole] = elem;
 }
 
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
+    uint32_t x = v;
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false));  // row_shr:1
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast:31
+    return x;
+}
+
+// Whole wavefront: the depths of the leaves (:247-259) by pointer jumping instead of one pass on one lane.  Every
+// internal node starts at distance 1 from its parent (the root at 0 from itself); a round replaces (distance to an
+// ancestor, that ancestor) by (distance to the ancestor's ancestor, ...) until every node's ancestor is the root: as
+// many rounds as the depth has bits.  The heap's array is free by now and holds the two 16-bit arrays.
+// ni = internal nodes (>= 1), CAP = the scratch's capacity.
+template <int CAP>
+__device__ __noinline__ void g_huff_depths_wave(const GHuffView v, const uint32_t ni, const int lane) {
+    using lds_u16 = __attribute__((address_space(3))) uint16_t;
+    using lds_u8 = __attribute__((address_space(3))) uint8_t;
+    const uint32_t N = v.n, root = ni - 1;
+    lds_u16* const anc = (lds_u16*)reinterpret_cast<uint16_t*>(v.heap);
+    lds_u16* const dist = anc + CAP;
+    const lds_u16* const in_left = (lds_u16*)v.in_left;
+    const lds_u16* const in_right = (lds_u16*)v.in_right;
+    lds_u8* const lengths = (lds_u8*)v.lengths;
+    for (uint32_t k = (uint32_t)lane; k < ni; k += kWave) {
+        anc[k] = (uint16_t)root;
+        dist[k] = k == root ? 0 : 1;
+    }
+    wave_sync();
+    for (uint32_t k = (uint32_t)lane; k < ni; k += kWave) {  // every internal node but the root is the child of one node
+        const uint32_t l = in_left[k], r = in_right[k];
+        if (l >= N) anc[l - N] = (uint16_t)k;
+        if (r >= N) anc[r - N] = (uint16_t)k;
+    }
+    wave_sync();
+    for (;;) {
+        bool moved = false;
+        for (uint32_t k = (uint32_t)lane; k < ni; k += kWave) {
+            const uint32_t a = anc[k];
+            const uint32_t da = dist[a], aa = anc[a];  // (read by every lane before any lane writes)
+            wave_sync();
+            if (a != root) {
+                dist[k] = (uint16_t)(dist[k] + da);
+                anc[k] = (uint16_t)aa;
+                moved = true;
+            }
+            wave_sync();
+        }
+        if (!__any(moved)) break;
+    }
+    uint32_t max_length = 0;
+    for (uint32_t k = (uint32_t)lane; k < ni; k += kWave) {
+        const uint32_t dch = (uint32_t)dist[k] + 1;
+        const uint32_t l = in_left[k], r = in_right[k];
+        if (l < N) {
+            lengths[l] = (uint8_t)dch;
+            max_length = max(max_length, dch);
+        }
+        if (r < N) {
+            lengths[r] = (uint8_t)dch;
+            max_length = max(max_length, dch);
+        }
+    }
+    max_length = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max_u32(max_length), kWave - 1);
+    if (lane == 0) v.hdr[2] = max_length;
+    wave_sync();
+}
+
 // ---- The merges on the whole wavefront: a sift is a path, and a path is found without touching the items. ----
 // sift_down_to_bottom follows the smaller child at every level, and sift_down_range follows the same path until the
 // moving item fits; which child is the smaller one is a property of the heap, not of the moving item.  So: every lane
@@ -1015,16 +1085,6 @@ struct GWriteArgs {
     const uint32_t* nblocks;
 };
 
-__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
-    uint32_t x = v;
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false));  // row_shr:1
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false));
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false));
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false));
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast:31
-    return x;
-}
 
 // table[idx] += 1 in the lanes that are `on` (some lane is): the lanes that agree with the first of them in one add.
 __device__ __forceinline__ void g_count(uint32_t* table, uint32_t idx, bool on, int lane) {
@@ -1283,9 +1343,10 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
             GW_T(8)
             g_huff_merges_wave<5>(vd, lane);
             GW_T(9)
-            if (lane < 2) {
-                const GHuffView vv = lane == 0 ? vl : vd;
-                if (vv.hdr[0] > 1) g_huff_depths(vv, vv.hdr[0] - 1);
+            {
+                const uint32_t hl_l = uni(lds.h.big.heap_len), hl_d = uni(lds.h.small.heap_len);
+                if (hl_l > 1) g_huff_depths_wave<288>(vl, hl_l - 1, lane);
+                if (hl_d > 1) g_huff_depths_wave<32>(vd, hl_d - 1, lane);
             }
         } else {
             g_huff_prepare<false>(vl, lane);
@@ -1324,7 +1385,10 @@ __global__ __launch_bounds__(kWave, 4) void deflate_write_kernel(GWriteArgs a) {
             GW_T(4)
             g_huff_merges_wave<5>(vc, lane);
             GW_T(10)
-            if (lane == 0 && vc.hdr[0] > 1) g_huff_depths(vc, vc.hdr[0] - 1);
+            {
+                const uint32_t hl_c = uni(lds.h.small.heap_len);
+                if (hl_c > 1) g_huff_depths_wave<32>(vc, hl_c - 1, lane);
+            }
             wave_sync();
             if (uni(lds.h.small.max_length) > 7) g_huff_limit(vc, lds.h.small.first, lane);
             g_huff_codes(vc, lds.clcl, lds.h.small.first, lane);
