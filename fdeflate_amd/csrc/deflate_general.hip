@@ -1056,14 +1056,14 @@ __device__ void g_huff_codes(const GHuffView& v, uint32_t* cl, uint32_t* first /
     for (uint32_t base = 0; base < v.n; base += kWave) {
         const uint32_t i = base + lane;
         const uint32_t l = i < v.n ? v.lengths[i] : 0;
-        uint32_t rank = 0, same = 0;
-        for (uint32_t len = 1; len <= 15; len++) {
-            const uint64_t m = __ballot(l == len);
-            if (l == len) {
-                rank = (uint32_t)__popcll(m & lanemask_lt(lane));
-                same = (uint32_t)__popcll(m);
-            }
+        // the lanes with this lane's length: one ballot per bit of the length instead of one per length
+        uint64_t m = ~(uint64_t)0;
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) {
+            const uint64_t bm = __ballot((l >> bit) & 1);
+            m &= ((l >> bit) & 1) ? bm : ~bm;
         }
+        const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt(lane)), same = (uint32_t)__popcll(m);
         uint32_t code = 0;
         if (l) code = first[l] + rank;
         wave_sync();
