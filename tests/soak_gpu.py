@@ -2,7 +2,8 @@
     python tests/soak_gpu.py <first seed> <end seed>
 General encoder (level 1 / RLE) and the PNG kernels against the oracle on random shapes and
 contents, with guard bytes; several images per wavefront for the PNG pipeline; zlib / ultra-fast streams whole,
-cut and damaged; cut streams' partial lengths; the resumable batch (FDH_SOAK_ONLY=resume: the last two only); the streaming object
+cut and damaged; cut streams' partial lengths; the resumable batch (FDH_SOAK_ONLY=resume: the last two only; =enc: the general
+encoder only); the streaming object
 at the reference's footprint (FDH_SOAK_ONLY=stream)."""
 import os, sys, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -345,6 +346,10 @@ ONLY = os.environ.get("FDH_SOAK_ONLY", "")
 for s in range(int(sys.argv[1]), int(sys.argv[2])):
     if ONLY == "stream":
         stream_round(8000 + s)
+        print("seed", s, "ok", flush=True)
+        continue
+    if ONLY == "enc":  # the general encoder alone (new seeds: the default rounds use 1000 + s)
+        enc_round(9000 + s)
         print("seed", s, "ok", flush=True)
         continue
     if ONLY == "resume":
