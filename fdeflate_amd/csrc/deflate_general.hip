@@ -1124,7 +1124,7 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
     };
     const uint32_t mlast = m1 ? m1 - 1 : 0;  // (the slice has at least two records, used or not)
     uint32_t mc = m0, covered = b0;  // next record to mark; end of the last back-reference so far
-    uint32_t zeros = 0;              // literal zeros of the frequency walk (wavefront-uniform)
+    uint32_t zeros = 0;              // literal zeros this lane met on the frequency walk
     uint32_t word_next = load4(b0 + 4 * lane);
     GMatchRec rnext = recs[min(mc + lane, mlast)];
     for (uint32_t c0 = b0; c0 < b1; c0 += kGChunk) {
@@ -1168,24 +1168,29 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
                 acc_a += sum;
                 acc_b += (len - p0) * sum - bytedot4(word, 0x03020100u, 0);
             }
-            // a literal: no back-reference starts there, and it lies behind the last one's end (A's, behind A)
+            // A literal: no back-reference starts there, and it lies behind the last one's end (A's, behind A).  As a
+            // mask of the four positions: those from `cov` on and in front of A, those from A's end on, without B's.
+            uint32_t litmask = 0xFu << min(max(cov, p0) - p0, 4u);
+            {
+                const uint32_t front = ~(0xFu << jA), back = 0xFu << min(endA - p0, 4u);
+                litmask = hasA ? ((litmask & front) | back) : litmask;
+                litmask &= hasB ? 0x7u : 0xFu;
+                litmask &= (1u << nact) - 1;
+            }
             bool lit[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t mkj = j == 0 ? mk0 : (j == 1 ? mk1 : (j == 2 ? mk2 : mk3));
-                lit[j] = mkj == 0 && (uint32_t)j < nact && p0 + j >= ((hasA && (uint32_t)j > jA) ? endA : cov);
-            }
+            for (int j = 0; j < 4; j++) lit[j] = (litmask >> j) & 1;
             uint64_t v0 = 0, v1 = 0;
             uint32_t nb = 0;
             if (!EMIT) {
 #pragma unroll
                 // An LDS atomic takes one pass per lane that shares its address, and filtered image bytes share a lot:
                 // a quarter of the literals are zeros (the zeros too isolated for a run), every run's distance code is
-                // the same.  The zeros are counted by ballot and added once per walk; of the back-references the lanes
+                // the same.  The zeros are counted per lane and added once per walk; of the back-references the lanes
                 // that agree with the first one are counted once.
                 for (int j = 0; j < 4; j++) {
                     const uint32_t byte = (word >> (8 * j)) & 0xFF;
-                    zeros += (uint32_t)__popcll(__ballot(lit[j] && byte == 0));
+                    zeros += (lit[j] && byte == 0) ? 1u : 0u;
                     if (lit[j] && byte != 0) atomicAdd(&lds.freq[byte], 1u);
                 }
                 if (__any(hasA)) {
@@ -1257,7 +1262,10 @@ __device__ void g_walk(GWriteLds& lds, BitRing& br, const uint8_t* in, const GMa
             }
         }
     }
-    if (!EMIT && lane == 0 && zeros) atomicAdd(&lds.freq[0], zeros);
+    if (!EMIT) {
+        zeros = wave_sum_u32(zeros);
+        if (lane == 0 && zeros) atomicAdd(&lds.freq[0], zeros);
+    }
     wave_sync();
 }
 
