@@ -40,6 +40,8 @@ FLAG_NO_LANDING = 0x10000    # tests / A-B: skip the landing decoder (inflate_se
 FLAG_LANDING_ONLY = 0x20000  # debug: run only the landing decoder (what it leaves stays PENDING)
 FLAG_NO_OVERLAP = 0x100000   # tests / A-B: the LZ-window kernel behind the canonical kernels, not beside them
 FLAG_NO_LEAN_WRITE = 0x80000  # tests / A-B: the landing decoder always takes the interval decoder's general writing pass
+FLAG_TAIL_LONG = 0x200000    # tests / A-B: behind the landing decoder always the five kernels of rounds 3-5
+FLAG_TAIL_SHORT = 0x400000   # tests / A-B: behind the landing decoder always the exact kernel alone
 
 
 class DecompressionError(Exception):

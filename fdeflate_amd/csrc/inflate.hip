@@ -265,16 +265,34 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
         }
     }
 }
+// What the landing decoder left over, told to the host without a synchronisation: a word pair in mapped host memory
+// ([0] the count, [1] a counter of reports), written by the first kernel behind the landing decoder.  The host reads
+// it at later calls and keeps the chain of launches behind the landing decoder short while nothing is left over
+// (fdh_launch_inflate).  Internal flag bits (cleared from the caller's flags): the kernel reports; the exact kernel's
+// hand-out counter is word 1 of its list (word 3 of that list was the landing decoder's own).
+__device__ uint32_t* g_tail_report = nullptr;
+constexpr uint32_t kFlagTailReport = 0x20000000u, kFlagTailCounter1 = 0x40000000u;
+__device__ __forceinline__ void tail_report(uint32_t count) {
+    uint32_t* const rep = g_tail_report;
+    if (rep) {
+        rep[0] = count;
+        rep[1] = rep[1] + 1;
+        __threadfence_system();
+    }
+}
+
 __global__ __launch_bounds__(kWave) void inflate_general_kernel(InflateBatchArgs a) {
     __shared__ GeneralLds lds;
     if (a.list) {  // only the streams a kernel in front has listed as left over, handed out by a counter
         const uint32_t cnt = a.list[0];
+        if ((a.flags & kFlagTailReport) && blockIdx.x == 0 && threadIdx.x == 0) tail_report(cnt);
+        const int cw = (a.flags & kFlagTailCounter1) ? 1 : 3;
         // (the first item of a workgroup is its own index, the following ones come from a counter: an
         // empty list costs no atomic -- four thousand of them on one address are 80 us)
         for (uint32_t i = blockIdx.x; i < cnt;) {
             general_one(a, lds, a.list[4 + i]);
             wave_sync();
-            if (threadIdx.x == 0) i = atomicAdd(&a.list[3], 1u) + gridDim.x;
+            if (threadIdx.x == 0) i = atomicAdd(&a.list[cw], 1u) + gridDim.x;
             i = uni(i);
         }
         return;
@@ -751,6 +769,7 @@ __global__ __launch_bounds__(1024) void stream_order_kernel(const uint8_t* in, c
 // wavefront, one workgroup of 16 persistent wavefronts per CU with all of its LDS.
 __global__ __launch_bounds__(kS2Waves* kWave, 4) void inflate_seg2_kernel(SegArgs a) {
     __shared__ Seg2Lds lds;
+    if (a.src_list && (a.flags & kFlagTailReport) && blockIdx.x == 0 && threadIdx.x == 0) tail_report(a.src_list[0]);
     if (a.src_list && a.src_list[0] == 0) return;  // the landing decoder left nothing over: do not even stage the table
     // the hand-scheduled loops address the table from LDS offset 0 (`raw & 0x3ffc` IS the address)
     if (lds_offset(lds.lit) != 0) __builtin_trap();
@@ -972,7 +991,21 @@ static fdh::CanonTables* g_canon_dev[64] = {};
 static uint32_t* g_span_pool[64] = {};  // per device: scratch of the span decoder (never freed)
 static int g_cu_count[64] = {};         // per device: compute units (0 = not asked yet)
 static hipStream_t g_side_stream[64] = {};  // per device: the stream the LZ-window kernel runs on beside the canonical kernels
-static std::mutex g_dev_mutex;          // guards the three per-device caches above
+static std::mutex g_dev_mutex;          // guards the per-device caches above and below
+// What the landing decoder leaves over, as the kernels report it (g_tail_report): while the reports say "next to nothing"
+// the call launches ONE kernel behind the landing decoder (the exact kernel, which takes any stream) instead of five (the
+// interval, segment and tile decoders and the two exact kernels: each launch costs ~10 us of the chain when its list is
+// empty -- 60 us of a 2.6 ms call).  The latest report decides: more than kTailFew streams left over, the long chain.
+// A hint only: every stream is decoded either way, a wrong guess costs time (the exact kernel is slow).
+struct TailHint {
+    volatile uint32_t* rep = nullptr;  // mapped host memory
+    uint32_t seen = 0;                 // rep[1] at the last look
+    int streak = 0;
+    bool short_chain = false;
+    bool tried = false;
+};
+static TailHint g_tail[64];
+constexpr uint32_t kTailFew = 16;
 
 // Scratch of a call (lists, check points, records): stream-ordered allocations from a pool of the library's own that
 // KEEPS what is freed (release threshold = everything).  With the device's default pool -- which hands its memory back
@@ -1036,8 +1069,48 @@ extern "C" int fdh_launch_canon_build(hipStream_t stream, uint32_t* host_status)
     if (e == hipSuccess && ordinal >= 0 && ordinal < 64) {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
         g_canon_dev[ordinal] = dev;
+        // the word pair the kernels behind the landing decoder report to (optional: without it every call takes the long chain)
+        TailHint& h = g_tail[ordinal];
+        if (!h.tried) {
+            h.tried = true;
+            uint32_t* hp = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&hp), 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess && hp) {
+                hp[0] = hp[1] = hp[2] = hp[3] = 0;
+                uint32_t* dp = nullptr;
+                if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dp), hp, 0) == hipSuccess && dp &&
+                    hipMemcpyToSymbol(HIP_SYMBOL(fdh::g_tail_report), &dp, sizeof(dp)) == hipSuccess) {
+                    h.rep = hp;
+                } else {
+                    (void)hipGetLastError();
+                    (void)hipHostFree(hp);
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
     }
     return (int)e;
+}
+
+// (introspection: the last report's count, the number of reports, the streak of small ones, the mode)
+extern "C" int fdh_debug_tail_state(unsigned int* out4) {
+    int dev = 0;
+    if (!out4 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    const TailHint& h = g_tail[dev];
+    out4[0] = h.rep ? h.rep[0] : 0xFFFFFFFFu;
+    out4[1] = h.rep ? h.rep[1] : 0xFFFFFFFFu;
+    out4[2] = (unsigned int)h.streak;
+    out4[3] = h.short_chain ? 1u : 0u;
+    return 0;
+}
+
+// (introspection, tests: 1 = the short chain behind the landing decoder is in use on this device, 0 = the long one)
+extern "C" int fdh_debug_tail_mode(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    return g_tail[dev].short_chain ? 1 : 0;
 }
 
 // Statuses of a batch whose streams are taken up at resume points: PENDING_RESUME where there is one, PENDING elsewhere.
@@ -1067,6 +1140,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                                   uint32_t* out_len, uint32_t* status, uint32_t* adler, uint64_t n, uint32_t flags,
                                   void* resume_io, hipStream_t stream) {
     if (n == 0) return 0;
+    flags &= ~(fdh::kFlagTailReport | fdh::kFlagTailCounter1);  // (internal)
     fdh::InflateBatchArgs a{in, in_off, out, out_off, out_len, status, adler, n, flags, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                             static_cast<uint4*>(resume_io)};
     if (resume_io && (flags & 0x8000u)) {
@@ -1273,6 +1347,43 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 }
                 sa.src_list = list + list3_at;
                 sa.list = list;
+            }
+            if (seg3 && overlap) {
+                // how many streams the landing decoder has been leaving over lately (TailHint)
+                bool short_chain = false, report = false;
+                {
+                    std::lock_guard<std::mutex> lock(g_dev_mutex);
+                    TailHint& h = g_tail[ordinal & 63];
+                    if (h.rep) {
+                        report = true;
+                        const uint32_t seq = h.rep[1], left = h.rep[0];
+                        if (seq != h.seen) {  // (a caller that enqueues calls faster than they run sees few reports: the latest one decides)
+                            h.seen = seq;
+                            h.streak = left > kTailFew ? 0 : h.streak + 1;
+                            h.short_chain = left <= kTailFew;
+                        }
+                        short_chain = h.short_chain;
+                    }
+                }
+                if (flags & 0x200000u) short_chain = false;  // FDH_FLAG_TAIL_LONG
+                if (flags & 0x400000u) short_chain = true;   // FDH_FLAG_TAIL_SHORT
+                if (short_chain) {  // the exact kernel alone on what the landing decoder listed, then the join
+                    a.only_pending = 1;
+                    a.resume = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(list) + words_al * sizeof(uint32_t) + ckpt_bytes + lzck_bytes);
+                    a.list = list + list3_at;
+                    a.flags = flags | fdh::kFlagTailCounter1 | (report ? fdh::kFlagTailReport : 0u);
+                    hipLaunchKernelGGL(fdh::inflate_general_kernel, dim3((unsigned)std::min<uint64_t>(n, 1024)), dim3(fdh::kWave), 0, stream, a);
+                    e = hipGetLastError();
+                    a.flags = flags;
+                    a.list = nullptr;
+                    const hipError_t ej = hipStreamWaitEvent(stream, ev_join, 0);
+                    (void)hipEventDestroy(ev_join);
+                    if (e == hipSuccess) e = ej;
+                    if (e != hipSuccess) (void)hipStreamSynchronize(side);  // (the scratch is about to go)
+                    (void)hipFreeAsync(list, stream);
+                    return (int)e;
+                }
+                if (report) sa.flags = flags | fdh::kFlagTailReport;
             }
             hipLaunchKernelGGL(fdh::inflate_seg2_kernel, dim3(s2blocks), dim3(fdh::kS2Waves * fdh::kWave), 0, stream, sa);
             e = hipGetLastError();

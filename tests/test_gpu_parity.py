@@ -249,6 +249,67 @@ def test_landing_decoder_flat_stretches(harness):
             assert int(ln_[i]) == rl[i] and outs[i][:rl[i]].tobytes() == ro[i] and int(ad[i]) == ra[i], (name, flags)
 
 
+def test_chain_behind_the_landing_decoder_long_short_and_chosen(harness):
+    """What the landing decoder leaves over goes through five kernels (interval, segment, tile decoders, two exact kernels)
+    or -- while recent calls left next to nothing -- through the exact kernel alone (fdh_launch_inflate, TailHint: the
+    kernels report the count to mapped host memory, no synchronisation).  A batch large enough for the ordered path
+    (16 384 streams and more), bench buffers, forty of them replaced by streams the landing decoder passes on (thousands
+    of equal literals in a row): forced long, forced short and chosen, every stream must come back as it went in (the
+    oracle checks a sample and the hard ones); and the choice must follow the reports -- short after calls that left
+    nothing, long again after one that left many."""
+    import ctypes as C
+    import torch
+    import bench
+    import fdeflate_amd as fd
+    from fdeflate_amd import synth, _lib, api
+    lib = _lib.lib()
+    r = np.random.default_rng(707)
+    n, L, dev = 16400, 65536, torch.device("cuda", 0)
+    r_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    clean = synth.gen_batch_torch(50000, n, L, device=dev)
+    mixed = clean.clone()
+    hard_at = sorted(int(x) for x in r.choice(n, 40, replace=False))
+    for k in hard_at:
+        z = r.integers(0, 256, L, dtype=np.uint8)
+        z[r.random(L) < 0.3] = 0
+        a = int(r.integers(0, 40000))
+        z[a:a + int(r.integers(6000, 20000))] = int(r.integers(1, 256))
+        mixed[k] = torch.from_numpy(z).to(dev)
+
+    def state():
+        a = (C.c_uint * 4)()
+        assert lib.fdh_debug_tail_state(a) == 0
+        return list(a)
+
+    def run(raw, flags, sample):
+        comp, c_off, clen = bench.encode_ultrafast(raw, r_off, dev)
+        out = torch.full((n * L,), 0xA5, dtype=torch.uint8, device=dev)
+        ol, st, ad = fd.inflate_batch(comp, c_off, out, r_off, flags=flags)
+        torch.cuda.synchronize()
+        assert int((st != 0).sum()) == 0 and int((ol != L).sum()) == 0, (flags, int((st != 0).sum()))
+        assert torch.equal(out.view(n, L), raw), flags
+        ch, coh = comp.cpu().numpy(), c_off.cpu().numpy()
+        adh = ad.cpu().numpy().view(np.uint32)
+        for i in sample:
+            blob = ch[int(coh[i]):int(coh[i]) + int(clen[i])].tobytes()
+            s_, o_, a_ = ob.decompress_bounded(blob, L)
+            assert s_ == 0 and o_ == raw[i].cpu().numpy().tobytes() and a_ == int(adh[i]), (flags, i)
+
+    sample = list(range(0, n, 997)) + hard_at
+    run(mixed, api.FLAG_TAIL_LONG, sample)
+    run(mixed, api.FLAG_TAIL_SHORT, sample)
+    for _ in range(3):          # nothing left over, three times (each call synchronised): the short chain is chosen
+        run(clean, 0, sample[:4])
+    assert state()[3] == 1, state()
+    run(mixed, 0, hard_at)      # ... and it takes the forty streams as well (slowly); its report switches back
+    assert state()[0] >= 20, state()
+    run(clean, 0, sample[:4])
+    assert state()[3] == 0, state()
+    for _ in range(3):
+        run(clean, 0, sample[:4])
+    assert state()[3] == 1, state()
+
+
 def _lz_cases():
     """General zlib streams for the LZ-window kernel (inflate_lz.h): every zlib level and strategy on the
     bench's buffers (noisy, half zero, all zero), short and long inputs, several blocks, text, matches that
