@@ -42,6 +42,8 @@ FLAG_NO_OVERLAP = 0x100000   # tests / A-B: the LZ-window kernel behind the cano
 FLAG_NO_LEAN_WRITE = 0x80000  # tests / A-B: the landing decoder always takes the interval decoder's general writing pass
 FLAG_TAIL_LONG = 0x200000    # tests / A-B: behind the landing decoder always the five kernels of rounds 3-5
 FLAG_TAIL_SHORT = 0x400000   # tests / A-B: behind the landing decoder always the exact kernel alone
+FLAG_ORDER_ONCE = 0x800000   # tests / A-B: the streams without the ultra-fast prefix listed in one launch, in no order
+FLAG_ORDER_TWICE = 0x1000000  # tests / A-B: ... in two, the long ones first
 
 
 class DecompressionError(Exception):

@@ -272,11 +272,11 @@ __device__ __forceinline__ void general_one(const InflateBatchArgs& a, GeneralLd
 // hand-out counter is word 1 of its list (word 3 of that list was the landing decoder's own).
 __device__ uint32_t* g_tail_report = nullptr;
 constexpr uint32_t kFlagTailReport = 0x20000000u, kFlagTailCounter1 = 0x40000000u;
-__device__ __forceinline__ void tail_report(uint32_t count) {
+__device__ __forceinline__ void tail_report(uint32_t count, int what = 0) {  // what: 0 the landing decoder's leftovers, 2 the other list
     uint32_t* const rep = g_tail_report;
     if (rep) {
-        rep[0] = count;
-        rep[1] = rep[1] + 1;
+        rep[what] = count;
+        rep[what + 1] = rep[what + 1] + 1;
         __threadfence_system();
     }
 }
@@ -543,6 +543,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FDH_LZ_WA
 void inflate_lz_kernel(InflateBatchArgs a) {
     __shared__ LzLds lds;
     const uint32_t cnt = a.list[0];
+    if ((a.flags & kFlagTailReport) && blockIdx.x == 0 && threadIdx.x == 0) tail_report(cnt, 2);
     for (uint32_t i = blockIdx.x; i < cnt;) {
         const uint32_t sid = a.list[4 + i];
         uint4 rec;
@@ -732,9 +733,10 @@ __global__ __launch_bounds__(1024) void stream_order_kernel(const uint8_t* in, c
     }
     // (the other streams' list is walked from the front by persistent wavefronts too: the long ones are listed by
     //  the first launch of this kernel, the short ones behind them by a second launch, `second`)
-    const bool other = valid && !canon && ((len >= thr) != (second != 0));
+    // (second == 2: one launch lists all of them, in no order -- taken while recent calls had next to none, TailHint)
+    const bool other = valid && !canon && (second == 2 || ((len >= thr) != (second != 0)));
     // class 0..3: the canonical streams by length (SegOrder); class 4: the other list
-    const uint32_t cls = other ? 4u : ((canon && !second) ? seg_order_class(len, mean) : 5u);
+    const uint32_t cls = other ? 4u : ((canon && second != 1) ? seg_order_class(len, mean) : 5u);
     const uint64_t below = (1ull << lane) - 1;
     uint32_t rank = 0;
 #pragma unroll
@@ -1000,8 +1002,10 @@ static std::mutex g_dev_mutex;          // guards the per-device caches above an
 struct TailHint {
     volatile uint32_t* rep = nullptr;  // mapped host memory
     uint32_t seen = 0;                 // rep[1] at the last look
+    uint32_t seen_others = 0;          // rep[3]
     int streak = 0;
     bool short_chain = false;
+    bool order_once = false;           // stream_order_kernel in one launch: the other list in no order (it has been next to empty)
     bool tried = false;
 };
 static TailHint g_tail[64];
@@ -1279,7 +1283,25 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
             if (ordered) {
                 uint32_t* order = list + list2_at + (n + 4);
                 uint32_t* counters = list + (n + 4);
-                for (uint32_t second = 0; second < 2; second++)
+                // (the other list's long streams first takes a launch of its own for the short ones: ~12 us of the chain in
+                //  front of the landing decoder, spent in vain while that list is as good as empty -- the LZ-window kernel
+                //  reports its count like the kernel behind the landing decoder does, TailHint)
+                bool once = false;
+                if (side) {
+                    std::lock_guard<std::mutex> lock(g_dev_mutex);
+                    TailHint& h = g_tail[ordinal & 63];
+                    if (h.rep) {
+                        const uint32_t seq = h.rep[3], others = h.rep[2];
+                        if (seq != h.seen_others) {
+                            h.seen_others = seq;
+                            h.order_once = others <= kTailFew;
+                        }
+                        once = h.order_once;
+                    }
+                }
+                if (flags & 0x800000u) once = true;    // FDH_FLAG_ORDER_ONCE
+                if (flags & 0x1000000u) once = false;  // FDH_FLAG_ORDER_TWICE
+                for (uint32_t second = once ? 2 : 0; second < (once ? 3u : 2u); second++)
                     hipLaunchKernelGGL(fdh::stream_order_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, stream, in, in_off, (uint32_t)n, order,
                                        counters, canon->hdr, status, fdh::kPending, sa.list2, second);
                 e = hipGetLastError();
@@ -1299,6 +1321,7 @@ extern "C" int fdh_launch_inflate(const uint8_t* in, const uint64_t* in_off, uin
                 if (forked) {
                     fdh::InflateBatchArgs b = a;
                     b.only_pending = 1;
+                    b.flags = flags | fdh::kFlagTailReport;  // (its list's count goes to the host's hint, if there is one)
                     b.list = list + list2_at;
                     b.list_out = list + list5_at;
                     b.lz_counter = list + (n + 4) + 4;  // (a spare word of stream_order_kernel's counters, zeroed above)

@@ -82,6 +82,8 @@ enum {
 #define FDH_FLAG_NO_OVERLAP      0x100000u /* tests/A-B: the LZ-window kernel runs behind the canonical kernels, not beside them */
 #define FDH_FLAG_TAIL_LONG       0x200000u /* tests/A-B: behind the landing decoder always the five kernels of rounds 3-5 (interval, segment, tile decoders, two exact kernels) */
 #define FDH_FLAG_TAIL_SHORT      0x400000u /* tests/A-B: behind the landing decoder always the exact kernel alone (the library chooses by what recent calls left over) */
+#define FDH_FLAG_ORDER_ONCE      0x800000u /* tests/A-B: stream_order_kernel lists the streams without the ultra-fast prefix in one launch, in no order */
+#define FDH_FLAG_ORDER_TWICE     0x1000000u /* tests/A-B: ... always in two (the long ones first), as in rounds 4-5 (the library chooses by how many recent calls had) */
 #define FDH_FLAG_LANDING_COUNT_ONLY 0x40000u /* debug: the landing decoder counts and leaves every stream PENDING */
 #define FDH_FLAG_SPANS          0x100u /* experimental: segment-parallel "span" decoder inside the 12-bit general kernel */
 

@@ -885,7 +885,8 @@ def test_ragged_batch_handed_out_long_streams_first(harness):
         comp_h[c_off_h[i]:c_off_h[i] + len(z)] = np.frombuffer(z, dtype=np.uint8)
         clen_h[i] = len(z)
     comp = torch.from_numpy(comp_h).cuda()
-    for flags in (0, fd.api.FLAG_NO_INTERVALS):
+    # (and the other list built in one launch / in two: the library chooses by what recent calls reported)
+    for flags in (0, fd.api.FLAG_NO_INTERVALS, fd.api.FLAG_ORDER_ONCE, fd.api.FLAG_ORDER_TWICE, fd.api.FLAG_ORDER_ONCE | fd.api.FLAG_TAIL_SHORT):
         out = torch.full((total + 64,), 0xA5, dtype=torch.uint8, device="cuda")
         out_len, status, adler = fd.inflate_batch(comp, c_off, out, r_off, flags=flags)
         torch.cuda.synchronize()
