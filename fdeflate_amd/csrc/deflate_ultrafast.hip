@@ -163,61 +163,98 @@ struct PngSource {
     // 8 filtered bytes from filtered offset `off` on (all inside the image), in two steps so that the
     // loads of a chunk are all unconditional and one tile ahead of their use (a load inside a branch
     // makes the compiler wait for EVERYTHING in flight at the join):
-    //   request  the usual case -- eight data bytes of one row with all their neighbours -- takes four
-    //            8-byte loads and the row's type; a chunk at a row's start or in the first row reads a
-    //            harmless in-bounds address instead and is redone byte by byte in `finish`
+    //   request  a chunk inside one row takes four 8-byte loads and the row's type: `fast` -- eight data
+    //            bytes with their neighbours --, `start` -- the type byte and the row's first seven data
+    //            bytes, whose left neighbours are the row's own bytes shifted and zeros (round 6: the rows
+    //            of the bench are 128 chunks, and the one at the start sent EVERY lane of every second tile
+    //            through the byte-by-byte code below: half of the kernel's filtering instructions) --,
+    //            `top` -- the first row, whose upper neighbours are zeros.  Any other chunk (it straddles two
+    //            rows, or starts inside a row's first pixel) reads a harmless in-bounds address instead and is
+    //            redone byte by byte in `finish`.
     //   finish   byte-wise arithmetic on all eight bytes at once (the type is the same for the chunk)
     struct Req {
         uint64_t rw, lw, uw, cw;
         uint32_t t, off;
-        bool fast;
+        bool fast, start, top;
     };
+    uint32_t magic;  // floor(2^32 / (rb + 1)): offsets are divided by the row length once per chunk
+    __device__ __forceinline__ void divide(uint32_t off, uint32_t& row, uint32_t& col) const {
+        const uint32_t rb1 = rb + 1;
+        row = __umulhi(off, magic);  // the quotient or one less (off < 2^32, magic >= 2^32 / rb1 - 1)
+        col = off - row * rb1;
+        if (col >= rb1) {
+            row++;
+            col -= rb1;
+        }
+    }
     __device__ __forceinline__ Req request(uint64_t off) const {
         Req q;
         const uint32_t rb1 = rb + 1;
         const uint32_t o32 = (uint32_t)off;  // (the filtered image is shorter than 2 GiB)
-        const uint32_t row = o32 / rb1, col = o32 - row * rb1;
+        uint32_t row, col;
+        divide(o32, row, col);
         q.off = o32;
-        q.fast = col >= 1 + bpp && col + 8 <= rb1 && row > 0;
+        const bool inrow = col + 8 <= rb1 && row < rows;
+        q.start = inrow && col == 0;  // (then rb >= 7: the load below reads one byte more, in the row or the next one / the tail)
+        q.fast = inrow && col >= 1 + bpp;
+        q.top = row == 0;
         const uint32_t trow = row < rows ? row : 0u;
         q.t = types[trow];
-        // (not fast: any address at which 8 bytes and the three neighbours are readable -- the same
+        // eight bytes must be readable at the row's start: not in the image's last seven bytes
+        if (q.start && (uint64_t)row * rb + 8 > (uint64_t)rows * rb) q.start = false;
+        // (neither: any address at which 8 bytes and the three neighbours are readable -- the same
         // place in the second row if there is one, else nothing is loaded)
-        const bool can = q.fast || (rows >= 2 && rb >= 8 + bpp);
-        const uint8_t* cur = q.fast ? pix + (uint64_t)row * rb + (col - 1) : pix + rb + bpp;
+        const bool direct = q.fast || q.start;
+        const bool can = direct || (rows >= 2 && rb >= 8 + bpp);
+        const uint8_t* cur = q.fast ? pix + (uint64_t)row * rb + (col - 1) : (q.start ? pix + (uint64_t)row * rb : pix + rb + bpp);
+        const bool up_ok = !direct || !q.top;
         q.rw = q.lw = q.uw = q.cw = 0;
         if (can) {
             q.rw = *reinterpret_cast<const uint64_t*>(cur);  // (the hardware handles misalignment)
-            q.lw = *reinterpret_cast<const uint64_t*>(cur - bpp);
-            q.uw = *reinterpret_cast<const uint64_t*>(cur - rb);
-            q.cw = *reinterpret_cast<const uint64_t*>(cur - rb - bpp);
+            q.lw = *reinterpret_cast<const uint64_t*>(q.start ? cur : cur - bpp);
+            q.uw = *reinterpret_cast<const uint64_t*>(up_ok ? cur - rb : cur);
+            q.cw = *reinterpret_cast<const uint64_t*>((up_ok && !q.start) ? cur - rb - bpp : cur);
         }
         return q;
     }
     __device__ __forceinline__ uint64_t finish(const Req& q, bool wanted) const {
-        const uint64_t rw = q.rw, lw = q.lw, uw = q.uw, cw = q.cw;
+        uint64_t rw = q.rw, lw = q.lw, uw = q.uw, cw = q.cw;
+        const bool direct = q.fast || q.start;
+        if (q.start) {  // [type, d0 .. d6]: the data bytes one place up, their left neighbours bpp places further
+            rw <<= 8;
+            uw <<= 8;
+            lw = (rw << (4 * bpp)) << (4 * bpp);
+            cw = (uw << (4 * bpp)) << (4 * bpp);
+        }
+        if (q.top) uw = cw = 0;
         const uint64_t H = 0x8080808080808080ull;
         auto sub8 = [&](uint64_t p, uint64_t r) { return ((p | H) - (r & ~H)) ^ ((p ^ ~r) & H); };  // p - r per byte
         uint64_t x = rw;
-        const uint32_t t = q.fast ? q.t : 0u;
+        const uint32_t t = direct ? q.t : 0u;
         if (t == 1) x = sub8(rw, lw);
         if (t == 2) x = sub8(rw, uw);
         if (t == 3) x = sub8(rw, (lw & uw) + (((lw ^ uw) >> 1) & 0x7F7F7F7F7F7F7F7Full));  // floor((a + b) / 2)
-        if (__any(t == 4)) {  // Paeth: byte by byte
-            uint64_t y = 0;
+        if (__any(t == 4)) {  // Paeth: byte by byte; |p - a| = |b - c|, |p - b| = |a - c|, |p - c| = |a + b - 2c|
+            uint32_t ylo = 0, yhi = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const uint32_t raw = (uint32_t)(rw >> (8 * j)) & 0xFF, a = (uint32_t)(lw >> (8 * j)) & 0xFF;
-                const uint32_t b = (uint32_t)(uw >> (8 * j)) & 0xFF, c = (uint32_t)(cw >> (8 * j)) & 0xFF;
-                const int p = (int)a + (int)b - (int)c;
-                const int pa = abs(p - (int)a), pb = abs(p - (int)b), pc = abs(p - (int)c);
-                const uint32_t pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                y |= (uint64_t)((raw - pr) & 0xFFu) << (8 * j);
+                const uint32_t sh = 8 * (j & 3);
+                const uint32_t r4 = j < 4 ? (uint32_t)rw : (uint32_t)(rw >> 32), l4 = j < 4 ? (uint32_t)lw : (uint32_t)(lw >> 32);
+                const uint32_t u4 = j < 4 ? (uint32_t)uw : (uint32_t)(uw >> 32), c4 = j < 4 ? (uint32_t)cw : (uint32_t)(cw >> 32);
+                const uint32_t raw = (r4 >> sh) & 0xFF, a = (l4 >> sh) & 0xFF, b = (u4 >> sh) & 0xFF, c = (c4 >> sh) & 0xFF;
+                const uint32_t pa = __builtin_amdgcn_sad_u8(b, c, 0u), pb = __builtin_amdgcn_sad_u8(a, c, 0u);
+                const uint32_t pc = __builtin_amdgcn_sad_u16(a + b, c << 1, 0u);
+                const uint32_t bc = pb <= pc ? b : c;
+                const uint32_t pr = (pa <= pb && pa <= pc) ? a : bc;
+                const uint32_t v = ((raw - pr) & 0xFFu) << sh;
+                if (j < 4) ylo |= v;
+                else yhi |= v;
             }
-            x = t == 4 ? y : x;
+            x = t == 4 ? (((uint64_t)yhi << 32) | ylo) : x;
         }
-        if (__any(wanted && !q.fast)) {  // a row's first chunk, the first row: byte by byte (loads: see above)
-            if (wanted && !q.fast) {
+        if (q.start) x = (x & ~(uint64_t)0xFF) | q.t;
+        if (__any(wanted && !direct)) {  // a chunk over two rows or inside a row's first pixel: byte by byte (loads: see above)
+            if (wanted && !direct) {
                 // all the bytes are requested before the first one is used: one trip to memory, not eight
                 const uint32_t rb1 = rb + 1;
                 uint32_t r = q.off / rb1, cc = q.off - r * rb1;
@@ -278,7 +315,7 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
 
     const uint8_t* in = a.in + a.in_off[sid];
     uint64_t len = a.in_off[sid + 1] - a.in_off[sid];
-    PngSource png{nullptr, nullptr, 0, 0, 0};
+    PngSource png{nullptr, nullptr, 0, 0, 0, 0};
     if (PNG) {  // the encoder's input: rows x (1 + row_bytes) filtered bytes
         const uint64_t plen = len, nrows = plen / a.row_bytes;
         const uint64_t tlen = a.types_off[sid + 1] - a.types_off[sid];
@@ -287,6 +324,7 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
         png.types = a.types + a.types_off[sid];
         png.rb = a.row_bytes;
         png.bpp = a.bpp;
+        png.magic = (uint32_t)(0x100000000ull / ((uint64_t)a.row_bytes + 1));
         png.rows = st ? 0u : (uint32_t)nrows;
         bool bad_type = false;
         for (uint32_t r = (uint32_t)lane; r < png.rows; r += kWave) bad_type = bad_type || png.types[r] > 4;
@@ -353,7 +391,7 @@ void deflate_ultrafast_kernel_t(DeflateBatchArgs a) {
     // put a full trip to memory into every tile.
     const uint32_t last_chunk = nchunks ? nchunks - 1 : 0;
     uint64_t x_next = 0;
-    PngSource::Req req{0, 0, 0, 0, 0, 0, true};  // PNG: the chunk of the tile after next, requested
+    PngSource::Req req{0, 0, 0, 0, 0, 0, true, false, false};  // PNG: the chunk of the tile after next, requested
     if (PNG) {
         if (nchunks) x_next = png.finish(png.request((uint64_t)min((uint32_t)lane, last_chunk) * 8), (uint32_t)lane < nchunks);
         if (nchunks) req = png.request((uint64_t)min((uint32_t)lane + kWave, last_chunk) * 8);

@@ -66,6 +66,20 @@ def png_round(seed):
         h = d_o.cpu().numpy(); npx = int(poff[-1])
         assert int(st.abs().sum()) == 0 and h[:npx].tobytes() == pbuf[:npx].tobytes() and np.all(h[npx:] == 0xEE), (seed, pw, "unfilter", bpp, row_bytes)
 
+    # the filters fused into the ultra-fast encoder: pixel rows in, the oracle's encoding of the oracle's filtered image out
+    bound = [int(fd.ultrafast_bound(len(f))) + 16 for f in filts]
+    ooff = np.zeros(len(filts) + 1, dtype=np.int64); ooff[1:] = np.cumsum(bound)
+    d_z = torch.full((int(ooff[-1]),), 0xEE, dtype=torch.uint8, device="cuda")
+    ol, st = fd.png_filter_deflate_ultrafast_batch(d(pbuf) if pbuf.size else torch.zeros(1, dtype=torch.uint8, device="cuda"), d(poff.astype(np.int64)),
+                                                   d(tbuf) if tbuf.size else torch.zeros(1, dtype=torch.uint8, device="cuda"), d(toff.astype(np.int64)),
+                                                   d_z, d(ooff), row_bytes, bpp)
+    torch.cuda.synchronize()
+    h, oll = d_z.cpu().numpy(), ol.cpu().tolist()
+    assert int(st.abs().sum()) == 0, (seed, "fused status")
+    for i, f in enumerate(filts):
+        assert h[ooff[i]:ooff[i] + oll[i]].tobytes() == ob.compress_ultra_fast(f), (seed, "fused", i, bpp, row_bytes, len(f))
+        assert np.all(h[ooff[i] + oll[i]:ooff[i + 1]] == 0xEE), (seed, "fused guard", i)
+
 def dec_round(seed):
     """zlib streams of every level / strategy over mixed data, whole, truncated and with a flipped
     byte, in exact / loose / short slots: status, length, bytes and checksum against the oracle."""
@@ -346,6 +360,10 @@ ONLY = os.environ.get("FDH_SOAK_ONLY", "")
 for s in range(int(sys.argv[1]), int(sys.argv[2])):
     if ONLY == "stream":
         stream_round(8000 + s)
+        print("seed", s, "ok", flush=True)
+        continue
+    if ONLY == "png":
+        png_round(12000 + s)
         print("seed", s, "ok", flush=True)
         continue
     if ONLY == "enc":  # the general encoder alone (new seeds: the default rounds use 1000 + s)
