@@ -427,7 +427,15 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
             regs[k] = v;
         }
     };
+    // A lane starts its row k at step 2 * kSlot + k * P + lane and needs the description of row k + 1 there (its lines are
+    // fetched ahead).  Until round 6 it was made right there -- an LDS search, 64-bit address arithmetic and the load of
+    // the row's type byte, waited for on the spot -- and as ONE lane starts a row at every step, every lane of the
+    // wavefront went through those ~90 instructions and that memory round trip at every step.  Now all lanes describe
+    // their row k + 2 together, once per P steps (when lane 0 starts its row k), and hand the description down a
+    // two-deep queue: a period of at least 64 steps lies between the load of a type byte and its use.
     PngPipeRow prev{nullptr, nullptr, 0, 0, 0, false, false}, cur = prev, next = describe(lane, 0);
+    PngPipeRow nn = prev, nn2 = describe(kWave + lane, next.img);
+    uint32_t cu = P - 2 * kSlot, ku = 0;  // lane 0's position in its period; the row period it is in
     // position in the period of row k (signed: negative long before the lane's first row); it reaches
     // P (= 0 of the next row) after lane + 16 steps -- two uniform steps ahead of the first chunk, one
     // to fetch its line and one to park it
@@ -445,12 +453,19 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
     // uniform step behind that writes its line
     const uint32_t steps = T ? ((kmax * P + kWave + 2 * kSlot + ((N + 7) & ~7u) + 7) & ~7u) + 1 : 0;
     for (uint32_t step = 0; step < steps; step++) {
+        if (cu == P) {  // lane 0 starts its row ku: every lane's row ku + 1 is due from now on, row ku + 2 is looked up
+            cu = 0;
+            nn = nn2;
+            nn2 = describe((ku + 2) * kWave + lane, nn.img);
+            ku++;
+        }
+        cu++;
         if (c == (int32_t)P) {  // this lane starts its next row
             c = 0;
             k++;
             prev = cur;
             cur = next;
-            next = describe((k + 1) * kWave + lane, cur.img);
+            next = nn;
             if (cur.valid) {
                 if (cur.type > 4) atomicMin(&lds.bad[cur.img], cur.r);
                 cur.produced = cur.type <= 4 && cur.r < lds.bad[cur.img];
