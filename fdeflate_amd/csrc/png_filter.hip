@@ -181,18 +181,62 @@ __global__ __launch_bounds__(kWave) void png_filter_kernel(PngArgs a) {
 }
 
 // `valid` bytes (1..16) at p as a 16-byte chunk, never reading behind them.
+// The first `valid` (< 16: else all) of sixteen bytes, the others untouched / zero: an 8-, a 4-, a 2- and a 1-byte access as
+// the bits of `valid` say, not a loop over the bytes -- ONE lane of the pipeline has a row's last, partial piece in hand at
+// every memory step, and a wavefront issues what one of its lanes executes (the byte loop: ~150 instructions per piece).
 __device__ __forceinline__ uint4 png_load_part(const uint8_t* p, uint32_t valid) {
     if (valid >= 16) return png_load16(p);
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t k = 0; k < valid; k++) w[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    uint64_t lo = 0, hi = 0, part = 0;
+    uint32_t at = 0, sh = 0;  // bytes read so far of this half; bits filled of `part`
+    if (valid & 8) {
+        __builtin_memcpy(&lo, p, 8);
+        at = 8;
+    }
+    if (valid & 4) {
+        uint32_t w;
+        __builtin_memcpy(&w, p + at, 4);
+        part = w;
+        at += 4;
+        sh = 32;
+    }
+    if (valid & 2) {
+        uint16_t h;
+        __builtin_memcpy(&h, p + at, 2);
+        part |= (uint64_t)h << sh;
+        at += 2;
+        sh += 16;
+    }
+    if (valid & 1) part |= (uint64_t)p[at] << sh;
+    if (valid & 8) hi = part;
+    else lo = part;
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 __device__ __forceinline__ void png_store_part(uint8_t* p, const uint4& v, uint32_t valid) {
     if (valid >= 16) {
         png_store16(p, v);
         return;
     }
-    for (uint32_t k = 0; k < valid; k++) p[k] = (uint8_t)png_byte(v, (int)k);
+    const uint64_t lo = ((uint64_t)v.y << 32) | v.x, hi = ((uint64_t)v.w << 32) | v.z;
+    uint64_t rest = lo;
+    uint32_t at = 0;
+    if (valid & 8) {
+        __builtin_memcpy(p, &lo, 8);
+        rest = hi;
+        at = 8;
+    }
+    if (valid & 4) {
+        const uint32_t w = (uint32_t)rest;
+        __builtin_memcpy(p + at, &w, 4);
+        rest >>= 32;
+        at += 4;
+    }
+    if (valid & 2) {
+        const uint16_t h = (uint16_t)rest;
+        __builtin_memcpy(p + at, &h, 2);
+        rest >>= 16;
+        at += 2;
+    }
+    if (valid & 1) p[at] = (uint8_t)rest;
 }
 __device__ __forceinline__ uint32_t png_from_lane_below(uint32_t x) {  // lane j gets lane j - 1's value (lane 0: 0)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);

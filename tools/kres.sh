@@ -9,5 +9,6 @@ T=$(mktemp -d)
 TGT=$(/opt/rocm/llvm/bin/clang-offload-bundler --list --type=o --input=$T/fat.bin | grep gfx950 | head -1)
 /opt/rocm/llvm/bin/clang-offload-bundler --type=o --targets=$TGT --input=$T/fat.bin --output=$T/dev.o --unbundle
 /opt/rocm/llvm/bin/llvm-readelf --notes $T/dev.o | grep -E "\.name:|\.vgpr_count|\.vgpr_spill_count|\.sgpr_spill_count|\.private_segment_fixed_size|\.group_segment_fixed_size" \
-  | sed 's/^ *//' | awk '/^\.name:/{if (line) print line; line=$0; next} {line=line"  "$0} END{print line}' | grep -v "^\.name: *[a-z_]*$" | sort
+  | sed 's/^ *//' | awk '/^\.group_segment_fixed_size/{g=$0; next} /^\.name:/{if (line) print line; line=$0"  "g; next} {line=line"  "$0} END{print line}' | grep -v "^\.name: *[a-z_]*$" | sort
+# (the notes list a kernel's keys in alphabetical order: .group_segment_fixed_size comes BEFORE .name and belongs to the name behind it)
 rm -rf $T
