@@ -384,11 +384,19 @@ __global__ __launch_bounds__(kWave) void png_wave_kernel(PngArgs a) {
 // out the line it completed last -- eight full-width loads and stores per eight steps.
 constexpr uint32_t kPipeMaxChunks = 256;  // rows up to 4 KiB (the LDS row buffer)
 constexpr uint32_t kPipeMaxImages = 8;
-constexpr int kSlot = 2;  // 16-byte chunks per line slot (32 bytes): 12 KiB of LDS per wavefront, 13 wavefronts per CU
+constexpr int kSlot = 2;  // 16-byte chunks per line slot of the INPUT (32 bytes)
+#ifndef FDH_PNG_OUT_SLOT
+#define FDH_PNG_OUT_SLOT 4
+#endif
+// ... and of the output, what a lane stores at once: 64 bytes.  The kernel is bound by the cache-line transactions of its
+// loads and stores -- a 16-byte access per lane touches 64 lines per instruction (compiled without its stores it takes 3.0
+// instead of 6.6 ms, without its loads 3.7, without both 2.6) -- and four stores in a row to one or two lines merge better
+// than two now and two later (6.56 -> 6.16 ms; 128 bytes: 6.1-6.2 at 21 KiB of LDS; non-temporal stores: 14 ms).
+constexpr int kOut = FDH_PNG_OUT_SLOT;
 
 struct PngPipeLds {
     uint4 lin[kWave][2][kSlot];
-    uint4 lout[kWave][2][kSlot];
+    uint4 lout[kWave][2][kOut];
     uint64_t sbase[kPipeMaxImages + 1], dbase[kPipeMaxImages];  // offsets of the images' buffers (sbase[j + 1]: end of j's)
     uint32_t rowsum[kPipeMaxImages + 1];
     uint32_t bad[kPipeMaxImages];  // first row with a bad filter type, per image
@@ -535,21 +543,21 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
             // (the stores go out BEFORE the next line is requested: loads and stores share one in-order
             // counter, and the wait in front of the parking above is for everything issued -- with the
             // stores behind the loads it waited for the stores' round trip as well)
-            {   // write out the line of the slot that ended in (step - 8, step]
-                int32_t cfs = c - ph - kSlot;
+            if ((step & (kOut - 1)) == 0) {   // write out the line of the slot that ended in (step - kOut, step]
+                int32_t cfs = c - (c & (kOut - 1)) - kOut;
                 const bool back = cfs < 0;  // (that slot belongs to the row before)
                 if (back) cfs += (int32_t)P;
                 const PngPipeRow& d = back ? prev : cur;
                 const uint32_t kf = back ? k - 1 : k;
                 const uint32_t cf = (uint32_t)cfs;
                 if (d.valid && d.produced && cf < N) {
-                    const uint32_t par = (kf * (P / kSlot) + (cf / kSlot)) & 1;
-                    if ((uint64_t)(cf + kSlot) * 16 <= rb) {  // a line inside the row: plain stores
+                    const uint32_t par = (kf * (P / kOut) + (cf / kOut)) & 1;
+                    if ((uint64_t)(cf + kOut) * 16 <= rb) {  // a line inside the row: plain stores
 #pragma unroll
-                        for (int q = 0; q < kSlot; q++) png_store16(d.out + (uint64_t)(cf + q) * 16, lds.lout[lane][par][q]);
+                        for (int q = 0; q < kOut; q++) png_store16(d.out + (uint64_t)(cf + q) * 16, lds.lout[lane][par][q]);
                     } else
 #pragma unroll
-                    for (int q = 0; q < kSlot; q++) {
+                    for (int q = 0; q < kOut; q++) {
                         const uint64_t o16 = (uint64_t)(cf + q) * 16;
                         if (cf + q < N && o16 < rb) png_store_part(d.out + o16, lds.lout[lane][par][q], (uint32_t)min((uint64_t)16, rb - o16));
                     }
@@ -571,14 +579,14 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
         }
         const uint32_t cu = (uint32_t)c;
         const bool on = cur.valid && cur.produced && cu < N;  // (cur.valid is false while c is negative)
-        const uint32_t par = (k * (P / kSlot) + (cu / kSlot)) & 1;
+        const uint32_t par = (k * (P / kSlot) + (cu / kSlot)) & 1, par_out = (k * (P / kOut) + (cu / kOut)) & 1;
         uint4 u = make_uint4(png_from_lane_below(last.x), png_from_lane_below(last.y), png_from_lane_below(last.z), png_from_lane_below(last.w));
         if (on) {
             const uint4 f = lds.lin[lane][par][cu & (kSlot - 1)];
             if (lane == 0) u = png_rowbuf[cu];
             if (cur.r == 0) u = make_uint4(0, 0, 0, 0);
             last = png_chunk<BPP, true>(f, u, la, ua, m);
-            lds.lout[lane][par][cu & (kSlot - 1)] = last;
+            lds.lout[lane][par_out][cu & (kOut - 1)] = last;
             if (lane == kWave - 1) png_rowbuf[cu] = last;
         }
         c++;
