@@ -466,7 +466,11 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
     // reads of a row's lines stay inside its image's filtered bytes (+ the next row's, harmless)
     auto fetch = [&](const PngPipeRow& d, uint32_t ln, uint4(&regs)[kSlot]) {
         const uint8_t* const end = a.src + lds.sbase[d.img + 1];
-        if (d.valid && (uint64_t)(ln + 1) * (16 * kSlot) <= rb) {  // a line inside the row: plain loads
+        // A line inside the IMAGE's filtered bytes: plain loads.  (Until round 6: a line inside the ROW -- a row's last,
+        // partial line went the other way, and as one lane has such a line at every memory step, every step's loads were
+        // followed by that path's `s_waitcnt vmcnt(0)`: its zeros go to the registers the loads are in flight to.  What a
+        // plain load reads behind the row's end are the next row's bytes: they stay in positions that are never stored.)
+        if (d.valid && d.in + (uint64_t)(ln + 1) * (16 * kSlot) <= end) {
 #pragma unroll
             for (int k = 0; k < kSlot; k++) regs[k] = png_load16(d.in + (uint64_t)ln * (16 * kSlot) + (uint64_t)k * 16);
             return;
