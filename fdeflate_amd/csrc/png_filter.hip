@@ -386,17 +386,19 @@ constexpr uint32_t kPipeMaxChunks = 256;  // rows up to 4 KiB (the LDS row buffe
 constexpr uint32_t kPipeMaxImages = 8;
 constexpr int kSlot = 2;  // 16-byte chunks per line slot of the INPUT (32 bytes)
 #ifndef FDH_PNG_OUT_SLOT
-#define FDH_PNG_OUT_SLOT 4
+#define FDH_PNG_OUT_SLOT 8
 #endif
-// ... and of the output, what a lane stores at once: 64 bytes.  The kernel is bound by the cache-line transactions of its
-// loads and stores -- a 16-byte access per lane touches 64 lines per instruction (compiled without its stores it takes 3.0
-// instead of 6.6 ms, without its loads 3.7, without both 2.6) -- and four stores in a row to one or two lines merge better
-// than two now and two later (6.56 -> 6.16 ms; 128 bytes: 6.1-6.2 at 21 KiB of LDS; non-temporal stores: 14 ms).
+// ... and of the output: 128 bytes, stored TRANSPOSED (the step loop: eight lanes to a row).  The kernel's time follows its
+// occupancy and its memory instructions -- compiled without its stores it took 3.0 instead of 6.6 ms, without its loads 3.7,
+// without both 2.6 --: a lane storing its own row's bytes makes 64 pieces of 16 bytes in 64 lines per instruction.  A lane
+// storing 64 bytes at once (four stores in a row): 6.56 -> 6.16 ms; non-temporal stores: 14 ms; the eight rows whose 128-byte
+// slot is complete at a step stored by eight lanes each, from ONE buffer per lane: 6.5 -> 5.35 ms.
 constexpr int kOut = FDH_PNG_OUT_SLOT;
 
 struct PngPipeLds {
     uint4 lin[kWave][2][kSlot];
-    uint4 lout[kWave][2][kOut];
+    uint4 lout[kWave][kOut];   // (one buffer: a slot is stored at the step it is complete, before its owner's next chunk)
+    uint4 rdesc[kWave][2];     // per lane, row count & 1: where the row's output starts (x, y), whether it is produced (z)
     uint64_t sbase[kPipeMaxImages + 1], dbase[kPipeMaxImages];  // offsets of the images' buffers (sbase[j + 1]: end of j's)
     uint32_t rowsum[kPipeMaxImages + 1];
     uint32_t bad[kPipeMaxImages];  // first row with a bad filter type, per image
@@ -529,6 +531,42 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
             m = PngMasks(cur.type);
 #pragma unroll
             for (int q = 0; q < 8; q++) la[q] = ua[q] = 0;
+            const uint64_t op = reinterpret_cast<uint64_t>(cur.out);
+            lds.rdesc[lane][k & 1] = make_uint4((uint32_t)op, (uint32_t)(op >> 32), (cur.valid && cur.produced) ? 1u : 0u, 0u);
+        }
+        {   // ---- write-out, TRANSPOSED.  A lane's slot of kOut chunks (128 bytes) is complete when its position is a multiple of
+            //      kOut: at this step that is the lanes l = step - 2 kSlot (mod kOut), 64 / kOut rows.  Each of them is stored by the kOut
+            //      lanes of its group, 16 bytes apiece: one store instruction per step, whose 64 pieces are eight runs of 128
+            //      bytes (a lane storing its own row's bytes makes 64 pieces of 16 in 64 different lines).  The owner's position
+            //      and row count follow from this lane's own -- positions differ by the lane distance --, where its row's output
+            //      starts is in its rdesc entry.  The slot is read here, in front of the chunk its owner writes at this very
+            //      step: one buffer is enough.
+            wave_sync();
+            const uint32_t owner = (lane & ~(uint32_t)(kOut - 1)) | ((step - 2 * kSlot) & (kOut - 1)), q = lane & (kOut - 1);  // (a lane's position is step - lane - 2 kSlot)
+            int32_t co = c + (int32_t)lane - (int32_t)owner, ko = (int32_t)k;
+            if (co >= (int32_t)P) {
+                co -= (int32_t)P;
+                ko++;
+            } else if (co < 0) {
+                co += (int32_t)P;
+                ko--;
+            }
+            int32_t cfs = co - kOut;
+            const bool back = cfs < 0;  // (that slot belongs to the row before)
+            if (back) cfs += (int32_t)P;
+            const int32_t kk = back ? ko - 1 : ko;
+            const uint32_t cf = (uint32_t)cfs;
+            const uint64_t o16 = (uint64_t)(cf + q) * 16;
+            if (kk >= 0 && (co & (kOut - 1)) == 0 && cf + q < N && o16 < rb) {
+                const uint4 ds = lds.rdesc[owner][kk & 1];
+                if (ds.z) {
+                    const uint4 v = lds.lout[owner][q];
+                    uint8_t* const dst = reinterpret_cast<uint8_t*>(((uint64_t)ds.y << 32) | ds.x) + o16;
+                    const uint32_t nb = (uint32_t)min((uint64_t)16, rb - o16);
+                    if (nb == 16) png_store16(dst, v);
+                    else png_store_part(dst, v, nb);
+                }
+            }
         }
         if ((step & (kSlot - 1)) == 0) {
             const int32_t ph = c & (kSlot - 1);
@@ -543,29 +581,6 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
                 const uint32_t par = (k1 * (P / kSlot) + ((uint32_t)c1 / kSlot)) & 1;
 #pragma unroll
                 for (int q = 0; q < kSlot; q++) lds.lin[lane][par][q] = pf[q];
-            }
-            // (the stores go out BEFORE the next line is requested: loads and stores share one in-order
-            // counter, and the wait in front of the parking above is for everything issued -- with the
-            // stores behind the loads it waited for the stores' round trip as well)
-            if ((step & (kOut - 1)) == 0) {   // write out the line of the slot that ended in (step - kOut, step]
-                int32_t cfs = c - (c & (kOut - 1)) - kOut;
-                const bool back = cfs < 0;  // (that slot belongs to the row before)
-                if (back) cfs += (int32_t)P;
-                const PngPipeRow& d = back ? prev : cur;
-                const uint32_t kf = back ? k - 1 : k;
-                const uint32_t cf = (uint32_t)cfs;
-                if (d.valid && d.produced && cf < N) {
-                    const uint32_t par = (kf * (P / kOut) + (cf / kOut)) & 1;
-                    if ((uint64_t)(cf + kOut) * 16 <= rb) {  // a line inside the row: plain stores
-#pragma unroll
-                        for (int q = 0; q < kOut; q++) png_store16(d.out + (uint64_t)(cf + q) * 16, lds.lout[lane][par][q]);
-                    } else
-#pragma unroll
-                    for (int q = 0; q < kOut; q++) {
-                        const uint64_t o16 = (uint64_t)(cf + q) * 16;
-                        if (cf + q < N && o16 < rb) png_store_part(d.out + o16, lds.lout[lane][par][q], (uint32_t)min((uint64_t)16, rb - o16));
-                    }
-                }
             }
             {   // fetch the line of the slot entered in (step + 8, step + 16]
                 const int32_t d2 = ph ? 2 * kSlot - ph : 2 * kSlot;
@@ -583,14 +598,14 @@ __global__ __launch_bounds__(kWave) void png_pipe_kernel(PngArgs a, uint32_t per
         }
         const uint32_t cu = (uint32_t)c;
         const bool on = cur.valid && cur.produced && cu < N;  // (cur.valid is false while c is negative)
-        const uint32_t par = (k * (P / kSlot) + (cu / kSlot)) & 1, par_out = (k * (P / kOut) + (cu / kOut)) & 1;
+        const uint32_t par = (k * (P / kSlot) + (cu / kSlot)) & 1;
         uint4 u = make_uint4(png_from_lane_below(last.x), png_from_lane_below(last.y), png_from_lane_below(last.z), png_from_lane_below(last.w));
         if (on) {
             const uint4 f = lds.lin[lane][par][cu & (kSlot - 1)];
             if (lane == 0) u = png_rowbuf[cu];
             if (cur.r == 0) u = make_uint4(0, 0, 0, 0);
             last = png_chunk<BPP, true>(f, u, la, ua, m);
-            lds.lout[lane][par_out][cu & (kOut - 1)] = last;
+            lds.lout[lane][cu & (kOut - 1)] = last;
             if (lane == kWave - 1) png_rowbuf[cu] = last;
         }
         c++;
